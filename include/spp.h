@@ -1,0 +1,242 @@
+/*
+ * include/spp.h -- C ABI of the MI355X-native mini-batch GNN data path
+ * (libspp_hip.so), the drop-in boundary beneath SALIENT++'s `fast_sampler`
+ * module (reference: fast_sampler/fast_sampler.cpp:1280-1396 is the pybind11
+ * surface this replaces).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures: device buffers are `void*`
+ *     or typed pointers to HBM, streams are passed as `void*` (a hipStream_t),
+ *     0 / NULL means the null stream;
+ *   - every buffer is CALLER-OWNED unless stated otherwise; sampler/session
+ *     objects own only their internal workspace;
+ *   - every function returns SPP_OK (0) or a negative spp_status; the message
+ *     is available from spp_last_error() (thread-local);
+ *   - all functions are asynchronous w.r.t. the device unless documented as
+ *     blocking (spp_sampler_wait, spp_session_next);
+ *   - node ids are < 2^31 (the reference narrows to int32 inside sampling,
+ *     fast_sampler.cpp:196-199) and tensors at the boundary are int64, as
+ *     PyG / torch_sparse expect.
+ */
+#ifndef SPP_H
+#define SPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPP_ABI_VERSION 1
+#define SPP_MAX_HOPS 8
+#define SPP_MAX_PARTS 64
+
+typedef int spp_status;
+enum {
+  SPP_OK = 0,
+  SPP_ERR_INVALID = -1,   /* bad argument (TORCH_CHECK equivalents -> RuntimeError upstream) */
+  SPP_ERR_HIP = -2,       /* HIP runtime error */
+  SPP_ERR_CAPACITY = -3,  /* a batch exceeded the workspace the sampler was created for */
+  SPP_ERR_STATE = -4      /* call sequence error (e.g. export before wait) */
+};
+
+int spp_abi_version(void);
+const char* spp_last_error(void);
+/* number of visible HIP devices, or <0 when no device / runtime (the product path fails loudly) */
+int spp_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * a1  std::mt19937 stream (fast_sampler/sample_cpu.hpp:11, seeding
+ *     fast_sampler.cpp:994 `gen.seed(range.second*17+5)`): writes raw 32-bit
+ *     outputs number skip .. skip+n-1 of mt19937(seed) to out_dev.
+ * ------------------------------------------------------------------------- */
+spp_status spp_mt19937_fill(uint32_t seed, int64_t skip, int64_t n, uint32_t* out_dev, void* stream);
+/* seed of the batch whose idx range ends at `stop` (fast_sampler.cpp:994) */
+uint32_t spp_batch_seed(int32_t stop);
+
+/* ------------------------------------------------------------------------- *
+ * a5  serial_index (fast_sampler.cpp:238-279):
+ *       dst[i, :] = src[idx[i], :]  for i < min(n_idx, n_out)
+ *     src is row-major [src_rows, row_bytes]; idx_elem_bytes is 8 (int64, the
+ *     reference's dtype) or 4 (int32).  Rows i >= n_idx of dst are left
+ *     untouched (the reference leaves them uninitialised).
+ * ------------------------------------------------------------------------- */
+spp_status spp_gather_rows(const void* src_dev, int64_t src_rows, int64_t row_bytes,
+                           const void* idx_dev, int idx_elem_bytes, int64_t n_idx, int64_t n_out,
+                           void* dst_dev, void* stream);
+
+/* to_row_major (fast_sampler.cpp:281-308): column-major [rows, cols] -> row-major */
+spp_status spp_to_row_major(const void* src_dev, int64_t rows, int64_t cols, int elem_bytes,
+                            void* dst_dev, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a2-a4  On-GPU multi-hop neighbour sampler: sample_adj (sample_cpu.hpp:25-143)
+ *        driven by multilayer_sample (fast_sampler.cpp:191-236).
+ *        Bit-exact MFG (n_id, per-hop rowptr/col) vs the CPU algorithm for the
+ *        same (seeds, fanouts, graph, rng seed).
+ * ------------------------------------------------------------------------- */
+typedef struct spp_sampler spp_sampler;
+
+typedef struct spp_sampler_cfg {
+  const int64_t* rowptr_dev;   /* int64[num_nodes+1], HBM resident           */
+  const int64_t* col_dev;      /* int64[nnz], HBM resident                   */
+  int64_t num_nodes;
+  int64_t nnz;
+  int32_t num_hops;            /* len(sizes) <= SPP_MAX_HOPS                 */
+  int64_t sizes[SPP_MAX_HOPS]; /* fanouts, e.g. {15,10,5}; <0 = all neighbours */
+  int64_t max_batch;           /* max number of seeds in one batch           */
+  int32_t num_slots;           /* independent batches that may be in flight  */
+  int32_t device;              /* HIP device ordinal                         */
+} spp_sampler_cfg;
+
+/* counts of one sampled batch; hops in OUTPUT order (outermost first, after the
+ * std::reverse at fast_sampler.cpp:224) */
+typedef struct spp_mfg_counts {
+  int64_t num_nodes;              /* U = len(n_id)                           */
+  int64_t num_seeds;
+  int32_t num_hops;
+  int64_t T[SPP_MAX_HOPS];        /* target rows of hop                      */
+  int64_t S[SPP_MAX_HOPS];        /* source nodes of hop                     */
+  int64_t E[SPP_MAX_HOPS];        /* sampled edges of hop                    */
+  int64_t draws;                  /* RNG outputs consumed                    */
+} spp_mfg_counts;
+
+/* caller-owned, exact-size destination buffers for one batch's MFG */
+typedef struct spp_mfg_out {
+  int64_t* n_id;                  /* int64[U]                                */
+  int64_t* rowptr[SPP_MAX_HOPS];  /* int64[T_h+1], output order              */
+  int64_t* col[SPP_MAX_HOPS];     /* int64[E_h],   output order              */
+} spp_mfg_out;
+
+spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
+void spp_sampler_destroy(spp_sampler* s);
+/* bytes of HBM workspace held by the sampler (all slots) */
+int64_t spp_sampler_workspace_bytes(const spp_sampler* s);
+
+/* Enqueue the sampling of one batch into `slot` on `stream`.
+ * seeds_dev: int64[n_seeds] in HBM.  The RNG stream is mt19937(rng_seed) with
+ * the first rng_skip outputs discarded (rng_skip = 0 for Session batches). */
+spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int64_t* seeds_dev,
+                              int64_t n_seeds, uint32_t rng_seed, int64_t rng_skip, void* stream);
+/* BLOCKING: waits until the batch in `slot` is sampled and returns its counts. */
+spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_counts* out);
+/* Write the slot's MFG into caller buffers (int64, reference layout) on `stream`. */
+spp_status spp_sampler_export(spp_sampler* s, int32_t slot, const spp_mfg_out* out, void* stream);
+/* Fused serial_index over the slot's node list (worker lines fast_sampler.cpp:1006-1010):
+ *   dst[i,:] = src[n_id[i],:] for i < n_rows   (n_rows = U for x, batch size for y) */
+spp_status spp_sampler_gather(spp_sampler* s, int32_t slot, const void* src_dev, int64_t src_rows,
+                              int64_t row_bytes, int64_t n_rows, void* dst_dev, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a10/a11  RangePartitionBook (range_partition_book.cpp:85-112) and Cache
+ *          (range_partition_book.cpp:116-195) lookups on device.
+ *          offsets_host: int64[P+1] on the HOST (P <= SPP_MAX_PARTS).
+ *          cache_map_dev: int32[cache_map_len] direct map, -1 = not cached.
+ * ------------------------------------------------------------------------- */
+spp_status spp_nid2partid(const int64_t* offsets_host, int32_t n_offsets, const int64_t* nids_dev,
+                          int64_t n, int64_t* out_dev, void* stream);
+spp_status spp_cache_build_map(const int64_t* cached_vertices_dev, int64_t n_cached,
+                               int32_t* cache_map_dev, int64_t cache_map_len, void* stream);
+spp_status spp_cache_lookup(const int32_t* cache_map_dev, int64_t cache_map_len,
+                            const int64_t* nids_dev, int64_t n, uint8_t* is_cached_dev /*nullable*/,
+                            int64_t* cache_nid_dev /*nullable*/, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a8/a9  per-batch ownership bucketing of the MFG node list
+ *        (worker distributed branch, fast_sampler.cpp:1017-1262).
+ *   parts_out_dev  int64[U]   concat(partition_nids[0..P-1])
+ *   cached_out_dev int64[U]   cache-local indices of hits (first counts[P] valid)
+ *   perm_out_dev   int64[U]   perm_partition_to_mfg
+ *   counts_out_dev int64[P+2] [len(parts[0..P-1]), n_cached, n_local_on_host]
+ *   cpu_local_out_dev int64[U] nullable: (v-off[rank])-x_gpu_rows of local rows
+ *                     living in host memory, MFG order
+ *   workspace: spp_partition_workspace_bytes(U) bytes of HBM scratch.
+ * ------------------------------------------------------------------------- */
+int64_t spp_partition_workspace_bytes(int64_t max_nodes);
+spp_status spp_partition_batch(const int64_t* n_id_dev, int64_t U, const int64_t* offsets_host,
+                               int32_t P, int32_t rank, int32_t use_cache,
+                               const int32_t* cache_map_dev, int64_t cache_map_len,
+                               int64_t x_gpu_rows, int64_t* parts_out_dev, int64_t* cached_out_dev,
+                               int64_t* perm_out_dev, int64_t* counts_out_dev,
+                               int64_t* cpu_local_out_dev, void* workspace_dev,
+                               int64_t workspace_bytes, void* stream);
+
+/* a16 (transferers.py:472-486) fused final assembly, replacing zeros+scatter+cat+permute:
+ *   x_out[i,:] = row perm[i] of the virtual concatenation
+ *                [ parts[0] rows | ... | parts[P-1] rows | cache rows ]
+ * where the rank-th segment is gathered straight from x_local (local id =
+ * n_id[i]-off[rank]), the cache segment from cache_feats[cached_nids], and every
+ * other segment m from recv_dev (rows received from peer m, packed in partition
+ * order with the own-rank segment absent). seg_start_host: int64[P+2] prefix of
+ * segment lengths in the virtual concatenation. */
+spp_status spp_assemble_features(const int64_t* n_id_dev, const int64_t* perm_dev, int64_t U,
+                                 const int64_t* seg_start_host, int32_t P, int32_t rank,
+                                 int64_t rank_offset, const void* x_local_dev, int64_t x_local_rows,
+                                 const void* recv_dev, const void* cache_feats_dev,
+                                 const int64_t* cached_nids_dev, int64_t row_bytes, void* x_out_dev,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * a6/a7  Session runtime (fast_sampler.cpp:533-936 Session, :963-1016 worker,
+ *        non-distributed branch).  The reference's CPU worker pool + MPMC queue
+ *        + semaphore back-pressure is replaced by `max_items_in_queue` batch
+ *        slots kept in flight on HIP streams; batches are delivered in index
+ *        order.  Batch ranges and per-batch seeds follow fast_sampler.cpp:587-627
+ *        and :994 exactly.
+ * ------------------------------------------------------------------------- */
+typedef struct spp_session spp_session;
+
+typedef struct spp_session_cfg {
+  const int64_t* rowptr_dev;
+  const int64_t* col_dev;
+  int64_t num_nodes;
+  int64_t nnz;
+  const int64_t* idx_dev;          /* int64[n_idx] seed nodes of this epoch, HBM */
+  int64_t n_idx;
+  int64_t batch_size;
+  int32_t num_hops;
+  int64_t sizes[SPP_MAX_HOPS];
+  int32_t skip_nonfull_batch;
+  int32_t force_exact_num_batches;
+  int64_t exact_num_batches;
+  int32_t max_items_in_queue;      /* batches in flight (slots)                */
+  int32_t num_streams;             /* HIP streams the slots are spread over (0 = default 4) */
+  int32_t device;
+} spp_session_cfg;
+
+typedef struct spp_batch_desc {
+  int64_t batch_index;
+  int32_t start, stop;             /* idx range, as PreparedSample's pair      */
+  int32_t slot;
+  spp_mfg_counts counts;
+} spp_batch_desc;
+
+spp_status spp_session_create(const spp_session_cfg* cfg, spp_session** out);
+void spp_session_destroy(spp_session* s);
+int64_t spp_session_num_total_batches(const spp_session* s);
+int64_t spp_session_num_consumed_batches(const spp_session* s);
+/* fills ranges (2*num_total_batches int32) -- the table of fast_sampler.cpp:587-627 */
+spp_status spp_session_batch_ranges(const spp_session* s, int32_t* out_start_stop);
+/* BLOCKING. Returns 1 and fills *out when the next batch (index order) is ready,
+ * 0 at end of epoch (the reference returns None), <0 on error. */
+int spp_session_next(spp_session* s, spp_batch_desc* out);
+/* Write the batch returned by the last spp_session_next into caller buffers on
+ * `stream`: MFG (as spp_sampler_export), optional x = x_src[n_id] and
+ * y = y_src[n_id[:stop-start]]; then recycle its slot (the next pending batch
+ * starts sampling into it, ordered after these copies). */
+spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
+                              const void* x_src_dev, int64_t x_rows, int64_t x_row_bytes, void* x_out_dev,
+                              const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,
+                              void* stream);
+/* total time spp_session_next spent blocked, microseconds, and number of blocking waits
+ * (fast_sampler.cpp:788-799 total_blocked_dur / total_blocked_occasions) */
+int64_t spp_session_blocked_us(const spp_session* s);
+int64_t spp_session_blocked_occasions(const spp_session* s);
+/* the sampler owned by the session (for spp_sampler_gather on the current slot etc.) */
+spp_sampler* spp_session_sampler(spp_session* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPP_H */

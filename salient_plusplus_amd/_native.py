@@ -1,0 +1,123 @@
+"""ctypes binding of libspp_hip.so (the C ABI declared in include/spp.h).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, the
+product path raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspp_hip.so")
+
+SPP_MAX_HOPS = 8
+SPP_MAX_PARTS = 64
+
+p = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+u32 = C.c_uint32
+
+
+class SamplerCfg(C.Structure):
+    _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
+                ("num_hops", i32), ("sizes", i64 * SPP_MAX_HOPS), ("max_batch", i64),
+                ("num_slots", i32), ("device", i32)]
+
+
+class MfgCounts(C.Structure):
+    _fields_ = [("num_nodes", i64), ("num_seeds", i64), ("num_hops", i32),
+                ("T", i64 * SPP_MAX_HOPS), ("S", i64 * SPP_MAX_HOPS), ("E", i64 * SPP_MAX_HOPS),
+                ("draws", i64)]
+
+
+class MfgOut(C.Structure):
+    _fields_ = [("n_id", p), ("rowptr", p * SPP_MAX_HOPS), ("col", p * SPP_MAX_HOPS)]
+
+
+class SessionCfg(C.Structure):
+    _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
+                ("idx_dev", p), ("n_idx", i64), ("batch_size", i64), ("num_hops", i32),
+                ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
+                ("force_exact_num_batches", i32), ("exact_num_batches", i64),
+                ("max_items_in_queue", i32), ("num_streams", i32), ("device", i32)]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("batch_index", i64), ("start", i32), ("stop", i32), ("slot", i32),
+                ("counts", MfgCounts)]
+
+
+# name -> (restype, argtypes); every symbol include/spp.h declares
+SIGNATURES = {
+    "spp_abi_version": (C.c_int, []),
+    "spp_last_error": (C.c_char_p, []),
+    "spp_device_count": (C.c_int, []),
+    "spp_mt19937_fill": (C.c_int, [u32, i64, i64, p, p]),
+    "spp_batch_seed": (u32, [i32]),
+    "spp_gather_rows": (C.c_int, [p, i64, i64, p, C.c_int, i64, i64, p, p]),
+    "spp_to_row_major": (C.c_int, [p, i64, i64, C.c_int, p, p]),
+    "spp_sampler_create": (C.c_int, [C.POINTER(SamplerCfg), C.POINTER(p)]),
+    "spp_sampler_destroy": (None, [p]),
+    "spp_sampler_workspace_bytes": (i64, [p]),
+    "spp_sampler_sample": (C.c_int, [p, i32, p, i64, u32, i64, p]),
+    "spp_sampler_wait": (C.c_int, [p, i32, C.POINTER(MfgCounts)]),
+    "spp_sampler_export": (C.c_int, [p, i32, C.POINTER(MfgOut), p]),
+    "spp_sampler_gather": (C.c_int, [p, i32, p, i64, i64, i64, p, p]),
+    "spp_nid2partid": (C.c_int, [p, i32, p, i64, p, p]),
+    "spp_cache_build_map": (C.c_int, [p, i64, p, i64, p]),
+    "spp_cache_lookup": (C.c_int, [p, i64, p, i64, p, p, p]),
+    "spp_partition_workspace_bytes": (i64, [i64]),
+    "spp_partition_batch": (C.c_int, [p, i64, p, i32, i32, i32, p, i64, i64, p, p, p, p, p, p, i64, p]),
+    "spp_assemble_features": (C.c_int, [p, p, i64, p, i32, i32, i64, p, i64, p, p, p, i64, p, p]),
+    "spp_session_create": (C.c_int, [C.POINTER(SessionCfg), C.POINTER(p)]),
+    "spp_session_destroy": (None, [p]),
+    "spp_session_num_total_batches": (i64, [p]),
+    "spp_session_num_consumed_batches": (i64, [p]),
+    "spp_session_batch_ranges": (C.c_int, [p, p]),
+    "spp_session_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
+    "spp_session_export": (C.c_int, [p, C.POINTER(MfgOut), p, i64, i64, p, p, i64, i64, p, p]),
+    "spp_session_blocked_us": (i64, [p]),
+    "spp_session_blocked_occasions": (i64, [p]),
+    "spp_session_sampler": (p, [p]),
+}
+
+_lib = None
+
+
+class SppError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libspp_hip.so and type every entry point.  Raises if the extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SppError(
+                f"{LIB_PATH} is missing: build it with `python -m salient_plusplus_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.spp_abi_version() != 1:
+            raise SppError("libspp_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc < 0:
+        msg = load().spp_last_error()
+        raise SppError(msg.decode() if msg else f"libspp_hip error {rc}")
+    return rc
+
+
+def require_device():
+    n = load().spp_device_count()
+    if n <= 0:
+        msg = load().spp_last_error()
+        raise SppError("no usable HIP device for the MI355X data path: "
+                       + (msg.decode() if msg else "device count 0"))
+    return n

@@ -1,0 +1,791 @@
+// a2-a4 / K1: on-GPU multi-hop neighbour sampler, bit-exact with the sequential CPU algorithm of
+// the reference (sample_adj, fast_sampler/sample_cpu.hpp:25-143, driven by multilayer_sample,
+// fast_sampler/fast_sampler.cpp:191-236).
+//
+// What has to be reproduced:
+//   * one std::mt19937 stream per batch, consumed in scan order: target i of hop h (only if
+//     deg_i > fanout) uses draws  base_h + fanout * #{k < i : deg_k > fanout} ... (+fanout);
+//   * Robert-Floyd picks per target (sample_cpu.hpp:97-110);
+//   * local ids handed out in FIRST-SEEN order of the sequential scan (targets in order, picks in
+//     emission order) through a running map shared by all hops (sample_cpu.hpp:50-60);
+//   * each output row sorted by local id (sample_cpu.hpp:126).
+//
+// GPU formulation, per hop (T = nodes collected so far = targets, all counts stay on the device):
+//   k_hop_count   lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
+//   k_hop_scan    1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
+//   k_mt_advance  1 wavefront : extend the batch's mt19937 stream to exactly the draws hop h needs
+//   k_hop_pick    lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
+//                               col reads; node-table insert with atomicMin(T + edge position)
+//   k_hop_flag    lane/edge   : table value -> "is first occurrence" flag, workgroup flag sums
+//   k_hop_scan2   1 workgroup : scan of flag sums -> number of new nodes
+//   k_hop_assign  lane/edge   : rank of every first occurrence -> new local id, n_ids append,
+//                               table value finalised
+//   k_hop_rows    lane/target : local ids of the row, LDS rank-sort, out_col
+// The node table is an open-addressing hash table in HBM (64-bit slots: key<<32 | value) sized
+// 2x the worst-case node count, so it stays Infinity-Cache resident; value < T means "final local
+// id", value >= T means "T + position of the earliest edge that reaches this node in this hop".
+//
+// Hops with fanout < 0 (all neighbours) or fanout > 32 take a generic path (edge-parallel expand,
+// hipcub segmented sort, one host sync per hop to size the launch).
+#include "spp_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace spp {
+
+spp_status gather_rows_i32(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n, void* dst,
+                           hipStream_t st);
+__device__ void mt19937_wave_fill(uint32_t* x, uint32_t seed, int64_t skip, int64_t n, uint32_t* out);
+
+constexpr int kNT = 256;         // workgroup size of the per-target / per-edge kernels
+constexpr int kFastMaxFanout = 32;
+constexpr int kScanNT = 1024;
+
+enum : int32_t { kErrEdgeCap = 1, kErrNodeCap = 2, kErrDrawCap = 4 };
+
+// device-resident bookkeeping of one batch slot (copied to pinned host memory after sampling)
+struct SlotState {
+  int32_t cnt[SPP_MAX_HOPS + 1];   // cnt[0] = #seeds, cnt[h+1] = #nodes after hop h (processing order)
+  int32_t E[SPP_MAX_HOPS];         // sampled edges of hop h
+  int32_t nsmp[SPP_MAX_HOPS];      // targets with deg > fanout in hop h
+  int64_t dbase[SPP_MAX_HOPS + 1]; // RNG draws consumed before hop h (relative to rng_skip)
+  int64_t gen_pos;                 // absolute number of mt19937 outputs generated so far
+  int32_t error;
+  int32_t pad;
+};
+
+struct SlotPtrs {
+  int32_t* n_ids;
+  int32_t* deg;
+  int64_t* rowstart;
+  int32_t* cval;       // neighbour node id of every edge position (later: local id, generic path)
+  uint32_t* eslot;     // node-table slot of every edge position
+  uint32_t* evals;     // node-table value seen by every edge position
+  int32_t* erank;      // exclusive rank among first occurrences (also Floyd scratch, generic path)
+  unsigned long long* table;
+  uint32_t tab_mask;
+  uint32_t* rng;       // draws rng_skip .. of the batch stream
+  uint32_t* mt_ring;   // saved 1024-word LDS ring of the generator
+  int32_t* bsum0;
+  int32_t* bsum1;
+  SlotState* st;
+  int32_t* out_rowptr[SPP_MAX_HOPS];  // processing order
+  int32_t* out_col[SPP_MAX_HOPS];
+};
+
+// ----------------------------------------------------------------------------------------------
+// node table
+// ----------------------------------------------------------------------------------------------
+template <bool kMax>
+__device__ __forceinline__ uint32_t table_upsert(unsigned long long* table, uint32_t mask, uint32_t key,
+                                                 uint32_t val) {
+  const unsigned long long entry = ((unsigned long long)key << 32) | val;
+  uint32_t h = hash_node(key) & mask;
+  for (;;) {
+    unsigned long long cur = table[h];
+    if (cur == kEmptySlot) {
+      cur = atomicCAS(&table[h], kEmptySlot, entry);
+      if (cur == kEmptySlot) return h;
+    }
+    if ((uint32_t)(cur >> 32) == key) {
+      if (kMax) atomicMax(&table[h], entry);
+      else atomicMin(&table[h], entry);
+      return h;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+// get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
+// seed keeps its LAST position -> atomicMax.
+__global__ __launch_bounds__(kNT) void k_seed_init(SlotPtrs s, const int64_t* __restrict__ seeds, int32_t n_seeds,
+                                                    int64_t rng_skip) {
+  const int i = blockIdx.x * kNT + threadIdx.x;
+  if (i == 0) {
+    s.st->cnt[0] = n_seeds;
+    s.st->dbase[0] = 0;
+    s.st->gen_pos = -1;  // generator not seeded yet
+    s.st->error = 0;
+  }
+  if (i < n_seeds) {
+    const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
+    s.n_ids[i] = v;
+    table_upsert<true>(s.table, s.tab_mask, (uint32_t)v, (uint32_t)i);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// per-target degree pass
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t& cnt, int32_t& smp) {
+  // sample_cpu.hpp:67-73 (f < 0: all), :91-94 (deg <= f: all), :97-110 (Floyd: f picks)
+  smp = (f >= 0 && deg > f) ? 1 : 0;
+  cnt = smp ? f : (deg > 0 ? deg : 0);
+}
+
+__global__ __launch_bounds__(kNT) void k_hop_count(SlotPtrs s, const int64_t* __restrict__ rowptr, int32_t h,
+                                                    int32_t f) {
+  __shared__ int32_t lds[2][kNT / kWave + 1];
+  const int32_t T = s.st->cnt[h];
+  const int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x;
+  if ((int64_t)blockIdx.x * kNT >= T) return;
+  int32_t cnt = 0, smp = 0;
+  if (i < T) {
+    const int32_t v = s.n_ids[i];
+    const int64_t rs = rowptr[v];
+    const int64_t re = rowptr[v + 1];
+    const int32_t deg = (int32_t)(re - rs);
+    s.deg[i] = deg;
+    s.rowstart[i] = rs;
+    target_counts(deg, f, cnt, smp);
+  }
+  int32_t tc, ts;
+  block_exclusive_scan<int32_t, kNT>(cnt, lds[0], &tc);
+  block_exclusive_scan<int32_t, kNT>(smp, lds[1], &ts);
+  if (threadIdx.x == 0) {
+    s.bsum0[blockIdx.x] = tc;
+    s.bsum1[blockIdx.x] = ts;
+  }
+}
+
+// in-place exclusive scan of n workgroup sums by ONE workgroup; returns the total to every thread
+__device__ int32_t scan_block_sums(int32_t* a, int32_t n, int32_t* lds) {
+  int32_t carry = 0;
+  for (int32_t base = 0; base < n; base += kScanNT) {
+    const int32_t i = base + threadIdx.x;
+    const int32_t v = (i < n) ? a[i] : 0;
+    int32_t tot;
+    const int32_t ex = block_exclusive_scan<int32_t, kScanNT>(v, lds, &tot);
+    if (i < n) a[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
+__global__ __launch_bounds__(kScanNT) void k_hop_scan(SlotPtrs s, int32_t h, int32_t f, int32_t ecap) {
+  __shared__ int32_t lds[kScanNT / kWave + 1];
+  const int32_t T = s.st->cnt[h];
+  const int32_t nblk = (T + kNT - 1) / kNT;
+  const int32_t E = scan_block_sums(s.bsum0, nblk, lds);
+  const int32_t S = scan_block_sums(s.bsum1, nblk, lds);
+  if (threadIdx.x == 0) {
+    s.st->E[h] = E;
+    s.st->nsmp[h] = S;
+    s.out_rowptr[h][T] = E;
+    if (E > ecap) atomicOr(&s.st->error, kErrEdgeCap);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// RNG: continue the batch's mt19937 stream (one wavefront) up to the draws hop h needs
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mt_temper_(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+__global__ __launch_bounds__(64) void k_mt_advance(SlotPtrs s, int32_t h, int32_t f, uint32_t seed, int64_t skip,
+                                                    int64_t dcap) {
+  __shared__ uint32_t x[1024];
+  const int lane = threadIdx.x;
+  SlotState* st = s.st;
+  int64_t pos = st->gen_pos;
+  // absolute number of outputs that must exist after this call
+  const int64_t need_rel = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
+  if (need_rel > dcap) {
+    if (lane == 0) atomicOr(&st->error, kErrDrawCap);
+    return;
+  }
+  const int64_t need = skip + need_rel;
+  if (pos < 0) {
+    if (lane == 0) {
+      uint32_t p = seed;  // std::mt19937::seed(value)
+      x[0] = p;
+      for (int i = 1; i < 624; ++i) {
+        p = 1812433253u * (p ^ (p >> 30)) + (uint32_t)i;
+        x[i] = p;
+      }
+    }
+    pos = 0;
+  } else {
+    if (pos >= need) return;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[lane + 64 * k] = s.mt_ring[lane + 64 * k];
+  }
+  __syncthreads();
+  // pos is always a multiple of 227: output i is temper(x[624 + i]), 227 outputs per step
+  for (; pos < need; pos += 227) {
+    uint32_t v[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int j = lane + 64 * m;
+      if (j < 227) {
+        const uint32_t nn = (uint32_t)((624 + pos + j) & 1023);
+        const uint32_t a = x[(nn - 624u) & 1023u];
+        const uint32_t b = x[(nn - 623u) & 1023u];
+        const uint32_t c = x[(nn - 227u) & 1023u];
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        v[m] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int j = lane + 64 * m;
+      if (j < 227) {
+        x[(uint32_t)((624 + pos + j) & 1023)] = v[m];
+        const int64_t i = pos + j;
+        if (i >= skip && i - skip < dcap) s.rng[i - skip] = mt_temper_(v[m]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s.mt_ring[lane + 64 * k] = x[lane + 64 * k];
+  if (lane == 0) st->gen_pos = pos;
+}
+
+// ----------------------------------------------------------------------------------------------
+// picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
+// ----------------------------------------------------------------------------------------------
+template <bool kGeneric>
+__global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
+                                                   int32_t f) {
+  __shared__ int32_t lds_scan[2][kNT / kWave + 1];
+  __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, column per lane
+  const int32_t T = s.st->cnt[h];
+  if ((int64_t)blockIdx.x * kNT >= T) return;
+  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  int32_t deg = 0, cnt = 0, smp = 0;
+  if (i < T) {
+    deg = s.deg[i];
+    target_counts(deg, f, cnt, smp);
+  }
+  int32_t tot;
+  const int32_t p0 = s.bsum0[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot);
+  const int32_t r0 = s.bsum1[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot);
+  if (i >= T) return;
+  s.out_rowptr[h][i] = p0;
+  if (s.st->error) return;
+  const uint32_t* rng = smp ? (s.rng + s.st->dbase[h] + (int64_t)f * r0) : s.rng;
+  if (kGeneric) {
+    // only the Floyd picks are produced here (into erank[p0..p0+f)); expansion is edge-parallel
+    if (smp) {
+      int32_t* mine = s.erank + p0;
+      for (int32_t k = 0; k < f; ++k) {
+        const int32_t j = deg - f + k;
+        const int32_t option = (int32_t)(rng[k] % (uint32_t)j);
+        bool found = false;
+        for (int32_t m = 0; m < k; ++m) found |= (mine[m] == option);
+        mine[k] = found ? j : option;
+      }
+    }
+    return;
+  }
+  const int64_t rs = s.rowstart[i];
+  const uint32_t T_u = (uint32_t)T;
+  const int tid = threadIdx.x;
+  if (smp) {
+    // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
+    // winner = option unless already chosen, then j.
+    for (int32_t k = 0; k < f; ++k) {
+      const int32_t j = deg - f + k;
+      const int32_t option = (int32_t)(rng[k] % (uint32_t)j);
+      bool found = false;
+      for (int32_t m = 0; m < k; ++m) found |= (chosen[m][tid] == option);
+      chosen[k][tid] = found ? j : option;
+    }
+  }
+  for (int32_t k = 0; k < cnt; ++k) {
+    const int32_t w = smp ? chosen[k][tid] : k;
+    const int32_t c = (int32_t)col[rs + w];
+    const int32_t p = p0 + k;
+    s.cval[p] = c;
+    s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, T_u + (uint32_t)p);
+  }
+}
+
+// generic path: one lane per edge position, row found by binary search in out_rowptr
+__global__ __launch_bounds__(kNT) void k_hop_expand_generic(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
+                                                             int32_t f) {
+  const int32_t T = s.st->cnt[h];
+  const int32_t E = s.st->E[h];
+  const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
+  if (p >= E) return;
+  const int32_t* rp = s.out_rowptr[h];
+  int32_t lo = 0, hi = T;  // largest i with rp[i] <= p
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (rp[mid] <= p) lo = mid; else hi = mid;
+  }
+  const int32_t i = lo;
+  const int32_t deg = s.deg[i];
+  const int32_t k = (int32_t)p - rp[i];
+  const int32_t w = (f >= 0 && deg > f) ? s.erank[p] : k;
+  const int32_t c = (int32_t)col[s.rowstart[i] + w];
+  s.cval[p] = c;
+  s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, (uint32_t)T + (uint32_t)p);
+}
+
+// ----------------------------------------------------------------------------------------------
+// first-occurrence ranking
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNT) void k_hop_flag(SlotPtrs s, int32_t h) {
+  __shared__ int32_t lds[kNT / kWave + 1];
+  const int32_t E = s.st->E[h];
+  if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
+  const uint32_t T = (uint32_t)s.st->cnt[h];
+  const int32_t p = blockIdx.x * kNT + threadIdx.x;
+  int32_t flag = 0;
+  if (p < E) {
+    const uint32_t v = (uint32_t)(s.table[s.eslot[p]] & 0xffffffffu);
+    s.evals[p] = v;
+    flag = (v == T + (uint32_t)p) ? 1 : 0;
+  }
+  int32_t tot;
+  block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
+  if (threadIdx.x == 0) s.bsum0[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanNT) void k_hop_scan2(SlotPtrs s, int32_t h, int32_t f, int32_t ucap) {
+  __shared__ int32_t lds[kScanNT / kWave + 1];
+  SlotState* st = s.st;
+  if (st->error) {
+    if (threadIdx.x == 0) {
+      st->cnt[h + 1] = st->cnt[h];
+      st->dbase[h + 1] = st->dbase[h];
+    }
+    return;
+  }
+  const int32_t E = st->E[h];
+  const int32_t nblk = (E + kNT - 1) / kNT;
+  const int32_t nnew = scan_block_sums(s.bsum0, nblk, lds);
+  if (threadIdx.x == 0) {
+    const int32_t U = st->cnt[h] + nnew;
+    st->cnt[h + 1] = U;
+    st->dbase[h + 1] = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
+    if (U > ucap) atomicOr(&st->error, kErrNodeCap);
+  }
+}
+
+__global__ __launch_bounds__(kNT) void k_hop_assign(SlotPtrs s, int32_t h) {
+  __shared__ int32_t lds[kNT / kWave + 1];
+  const int32_t E = s.st->E[h];
+  if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
+  const uint32_t T = (uint32_t)s.st->cnt[h];
+  const int32_t p = blockIdx.x * kNT + threadIdx.x;
+  int32_t flag = 0;
+  if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
+  int32_t tot;
+  const int32_t r = s.bsum0[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
+  if (p < E) {
+    s.erank[p] = r;
+    if (flag) {
+      const int32_t c = s.cval[p];
+      const uint32_t id = T + (uint32_t)r;
+      s.n_ids[id] = c;                                                    // n_ids.push_back(c)
+      s.table[s.eslot[p]] = ((unsigned long long)(uint32_t)c << 32) | id;  // final local id
+    }
+  }
+}
+
+__device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, int32_t p) {
+  const uint32_t v = s.evals[p];
+  return (v < T) ? (int32_t)v : (int32_t)(T + (uint32_t)s.erank[v - T]);
+}
+
+// fast path: one lane per target row, rank sort of <= 32 local ids staged in LDS
+__global__ __launch_bounds__(kNT) void k_hop_rows(SlotPtrs s, int32_t h) {
+  __shared__ int32_t a[kFastMaxFanout][kNT];
+  const int32_t T = s.st->cnt[h];
+  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  if (i >= T || s.st->error) return;
+  const int tid = threadIdx.x;
+  const int32_t p0 = s.out_rowptr[h][i];
+  const int32_t n = s.out_rowptr[h][i + 1] - p0;
+  for (int32_t k = 0; k < n; ++k) a[k][tid] = local_id_of(s, (uint32_t)T, p0 + k);
+  int32_t* out = s.out_col[h] + p0;
+  for (int32_t k = 0; k < n; ++k) {
+    const int32_t v = a[k][tid];
+    int32_t rank = 0;
+    for (int32_t j = 0; j < n; ++j) {
+      const int32_t w = a[j][tid];
+      rank += (w < v || (w == v && j < k)) ? 1 : 0;
+    }
+    out[rank] = v;  // std::sort of the row's local ids (sample_cpu.hpp:126)
+  }
+}
+
+// generic path: local id of every edge position (sorted afterwards by hipcub)
+__global__ __launch_bounds__(kNT) void k_hop_lids_generic(SlotPtrs s, int32_t h) {
+  const int32_t E = s.st->E[h];
+  const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
+  if (p >= E) return;
+  s.cval[p] = local_id_of(s, (uint32_t)s.st->cnt[h], (int32_t)p);
+}
+
+// ----------------------------------------------------------------------------------------------
+// export: widen the slot's int32 arrays into the caller's int64 tensors
+// ----------------------------------------------------------------------------------------------
+struct ExportSegs {
+  int32_t n;
+  const int32_t* src[2 * SPP_MAX_HOPS + 1];
+  int64_t* dst[2 * SPP_MAX_HOPS + 1];
+  int64_t start[2 * SPP_MAX_HOPS + 2];
+};
+
+__global__ __launch_bounds__(kNT) void k_export(ExportSegs g) {
+  const int64_t total = g.start[g.n];
+  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
+    int sgi = 0;
+    while (sgi + 1 < g.n && i >= g.start[sgi + 1]) ++sgi;
+    const int64_t k = i - g.start[sgi];
+    g.dst[sgi][k] = (int64_t)g.src[sgi][k];
+  }
+}
+
+}  // namespace spp
+
+// ================================================================================================
+// host side
+// ================================================================================================
+using namespace spp;
+
+struct SlotHost {
+  SlotPtrs p{};
+  hipEvent_t done = nullptr;
+  SlotState* host_state = nullptr;  // pinned
+  bool sampled = false;
+  bool waited = false;
+  int64_t ecap_dyn[SPP_MAX_HOPS];   // current capacity of out_col[h]
+  int64_t etmp_cap = 0;             // capacity of the per-edge temporaries
+  void* cub_tmp = nullptr;
+  size_t cub_tmp_bytes = 0;
+};
+
+struct spp_sampler {
+  spp_sampler_cfg cfg{};
+  int64_t tcap[SPP_MAX_HOPS + 1];   // node capacity before hop h (tcap[H] = Ucap)
+  int64_t ecap[SPP_MAX_HOPS];
+  int64_t dcap = 0;
+  bool generic[SPP_MAX_HOPS];
+  uint32_t tab_size = 0;
+  int64_t bytes = 0;
+  std::vector<SlotHost> slots;
+  std::vector<void*> allocs;
+};
+
+static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  SPP_HIP_TRY(hipMalloc(out, bytes));
+  s->allocs.push_back(*out);
+  s->bytes += (int64_t)bytes;
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out) {
+  SPP_REQUIRE(cfg && out, "spp_sampler_create: NULL argument");
+  SPP_REQUIRE(cfg->num_hops >= 1 && cfg->num_hops <= SPP_MAX_HOPS, "spp_sampler_create: num_hops %d not in [1,%d]",
+              cfg->num_hops, SPP_MAX_HOPS);
+  SPP_REQUIRE(cfg->rowptr_dev && (cfg->col_dev || cfg->nnz == 0), "spp_sampler_create: NULL graph");
+  SPP_REQUIRE(cfg->num_nodes > 0 && cfg->num_nodes < (1ll << 31), "spp_sampler_create: num_nodes %lld must be < 2^31",
+              (long long)cfg->num_nodes);
+  SPP_REQUIRE(cfg->max_batch > 0 && cfg->num_slots > 0, "spp_sampler_create: max_batch and num_slots must be > 0");
+  int ndev = spp_device_count();
+  SPP_REQUIRE(ndev > 0, "spp_sampler_create: no HIP device available (the on-GPU sampler has no CPU fallback)");
+  SPP_HIP_TRY(hipSetDevice(cfg->device));
+
+  auto* s = new spp_sampler();
+  s->cfg = *cfg;
+  const int H = cfg->num_hops;
+  const int64_t node_bound = cfg->num_nodes + cfg->max_batch;  // distinct nodes + duplicated seeds
+  s->tcap[0] = cfg->max_batch;
+  int64_t etmp = 1;
+  for (int h = 0; h < H; ++h) {
+    const int64_t f = cfg->sizes[h];
+    s->generic[h] = (f < 0 || f > kFastMaxFanout);
+    if (f >= 0) {
+      s->ecap[h] = s->tcap[h] * f;
+      s->tcap[h + 1] = std::min(s->tcap[h] * (1 + f), node_bound);
+      s->dcap += f * s->tcap[h];
+    } else {
+      // all-neighbour hop: sized on demand (host sync per hop); start small
+      s->ecap[h] = std::min<int64_t>(std::max<int64_t>(cfg->nnz, 1), 1 << 22);
+      s->tcap[h + 1] = node_bound;
+    }
+    etmp = std::max(etmp, s->ecap[h]);
+  }
+  const int64_t ucap = s->tcap[H];
+  SPP_REQUIRE(ucap + etmp < (1ll << 31), "spp_sampler_create: batch too large for 32-bit positions");
+  uint32_t tab = 1024;
+  while ((int64_t)tab < 2 * ucap) tab <<= 1;
+  s->tab_size = tab;
+  int64_t tmax = 0;
+  for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
+  const int64_t nblk_max = std::max(ceil_div(tmax, kNT), ceil_div(etmp, kNT)) + 1;
+
+  s->slots.resize(cfg->num_slots);
+  spp_status rc = SPP_OK;
+  for (auto& sl : s->slots) {
+    SlotPtrs& p = sl.p;
+#define A(ptr, type, count)                                                              \
+  if (rc == SPP_OK) {                                                                    \
+    void* v_ = nullptr;                                                                  \
+    rc = dev_alloc(s, &v_, sizeof(type) * (size_t)(count));                              \
+    ptr = static_cast<type*>(v_);                                                        \
+  }
+    A(p.n_ids, int32_t, ucap);
+    A(p.deg, int32_t, tmax);
+    A(p.rowstart, int64_t, tmax);
+    A(p.table, unsigned long long, tab);
+    A(p.rng, uint32_t, s->dcap + 256);
+    A(p.mt_ring, uint32_t, 1024);
+    A(p.bsum0, int32_t, nblk_max);
+    A(p.bsum1, int32_t, nblk_max);
+    A(p.st, SlotState, 1);
+    for (int h = 0; h < H; ++h) {
+      A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
+      A(p.out_col[h], int32_t, s->ecap[h]);
+      sl.ecap_dyn[h] = s->ecap[h];
+    }
+#undef A
+    p.tab_mask = tab - 1;
+    // per-edge temporaries are separately allocated so the generic path can grow them
+    if (rc == SPP_OK) {
+      sl.etmp_cap = etmp;
+      hipError_t e = hipSuccess;
+      e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.eslot, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.erank, sizeof(int32_t) * (size_t)etmp);
+      if (e != hipSuccess) {
+        set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
+        rc = SPP_ERR_HIP;
+      }
+      s->bytes += 16 * etmp;
+    }
+    if (rc == SPP_OK && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+      set_error("spp_sampler_create: hipEventCreate failed");
+      rc = SPP_ERR_HIP;
+    }
+    if (rc == SPP_OK && hipHostMalloc((void**)&sl.host_state, sizeof(SlotState), hipHostMallocDefault) != hipSuccess) {
+      set_error("spp_sampler_create: hipHostMalloc failed");
+      rc = SPP_ERR_HIP;
+    }
+    if (rc != SPP_OK) break;
+  }
+  if (rc != SPP_OK) {
+    spp_sampler_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return SPP_OK;
+}
+
+extern "C" void spp_sampler_destroy(spp_sampler* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& sl : s->slots) {
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.host_state) (void)hipHostFree(sl.host_state);
+    if (sl.p.cval) (void)hipFree(sl.p.cval);
+    if (sl.p.eslot) (void)hipFree(sl.p.eslot);
+    if (sl.p.evals) (void)hipFree(sl.p.evals);
+    if (sl.p.erank) (void)hipFree(sl.p.erank);
+    if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
+  }
+  for (void* a : s->allocs) (void)hipFree(a);
+  delete s;
+}
+
+extern "C" int64_t spp_sampler_workspace_bytes(const spp_sampler* s) { return s ? s->bytes : 0; }
+
+static spp_status grow_edge_scratch(spp_sampler* s, SlotHost& sl, int h, int64_t need) {
+  // generic path only; the stream has been synchronised by the caller
+  if (need > sl.etmp_cap) {
+    int64_t cap = std::max(need, sl.etmp_cap * 2);
+    (void)hipFree(sl.p.cval); (void)hipFree(sl.p.eslot); (void)hipFree(sl.p.evals); (void)hipFree(sl.p.erank);
+    sl.p.cval = nullptr; sl.p.eslot = nullptr; sl.p.evals = nullptr; sl.p.erank = nullptr;
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.eslot, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.erank, sizeof(int32_t) * (size_t)cap));
+    s->bytes += 16 * (cap - sl.etmp_cap);
+    sl.etmp_cap = cap;
+  }
+  if (need > sl.ecap_dyn[h]) {
+    int64_t cap = std::max(need, sl.ecap_dyn[h] * 2);
+    void* v = nullptr;
+    SPP_HIP_TRY(hipMalloc(&v, sizeof(int32_t) * (size_t)cap));
+    s->allocs.push_back(v);  // the old buffer is released at destroy
+    sl.p.out_col[h] = static_cast<int32_t*>(v);
+    s->bytes += 4 * cap;
+    sl.ecap_dyn[h] = cap;
+  }
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int64_t* seeds_dev, int64_t n_seeds,
+                                         uint32_t rng_seed, int64_t rng_skip, void* stream) {
+  SPP_REQUIRE(s, "spp_sampler_sample: NULL sampler");
+  SPP_REQUIRE(slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_sample: slot %d out of range", slot);
+  SPP_REQUIRE(n_seeds >= 0 && n_seeds <= s->cfg.max_batch, "spp_sampler_sample: n_seeds %lld exceeds max_batch %lld",
+              (long long)n_seeds, (long long)s->cfg.max_batch);
+  SPP_REQUIRE(seeds_dev || n_seeds == 0, "spp_sampler_sample: seeds_dev is NULL");
+  SPP_REQUIRE(rng_skip >= 0, "spp_sampler_sample: rng_skip must be >= 0");
+  SlotHost& sl = s->slots[slot];
+  hipStream_t st = as_stream(stream);
+  const int H = s->cfg.num_hops;
+  const int64_t* rowptr = s->cfg.rowptr_dev;
+  const int64_t* col = s->cfg.col_dev;
+
+  SPP_HIP_TRY(hipMemsetAsync(sl.p.table, 0xFF, sizeof(unsigned long long) * (size_t)s->tab_size, st));
+  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)std::max<int64_t>(1, ceil_div(n_seeds, kNT))), dim3(kNT), 0, st, sl.p,
+                     seeds_dev, (int32_t)n_seeds, rng_skip);
+  for (int h = 0; h < H; ++h) {
+    const int32_t f = (int32_t)s->cfg.sizes[h];
+    const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
+    hipLaunchKernelGGL(k_hop_count, dim3(gt), dim3(kNT), 0, st, sl.p, rowptr, h, f);
+    // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
+    const int32_t ecap_dev = s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(sl.ecap_dyn[h], 0x7fffffff);
+    hipLaunchKernelGGL(k_hop_scan, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, ecap_dev);
+    if (f > 0)
+      hipLaunchKernelGGL(k_mt_advance, dim3(1), dim3(64), 0, st, sl.p, h, f, rng_seed, rng_skip, s->dcap);
+    unsigned ge;
+    if (!s->generic[h]) {
+      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f);
+      ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
+    } else {
+      // slow path: the edge count is needed on the host to size launches and scratch
+      SPP_HIP_TRY(hipMemcpyAsync(sl.host_state, sl.p.st, sizeof(SlotState), hipMemcpyDeviceToHost, st));
+      SPP_HIP_TRY(hipStreamSynchronize(st));
+      const int64_t E = sl.host_state->E[h];
+      if (sl.host_state->error) break;
+      SPP_TRY(grow_edge_scratch(s, sl, h, E));
+      ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
+      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f);
+      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge), dim3(kNT), 0, st, sl.p, col, h, f);
+    }
+    hipLaunchKernelGGL(k_hop_flag, dim3(ge), dim3(kNT), 0, st, sl.p, h);
+    hipLaunchKernelGGL(k_hop_scan2, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, (int32_t)s->tcap[H]);
+    hipLaunchKernelGGL(k_hop_assign, dim3(ge), dim3(kNT), 0, st, sl.p, h);
+    if (!s->generic[h]) {
+      hipLaunchKernelGGL(k_hop_rows, dim3(gt), dim3(kNT), 0, st, sl.p, h);
+    } else {
+      const int64_t E = sl.host_state->E[h];
+      const int32_t T = sl.host_state->cnt[h];
+      if (E > 0) {
+        hipLaunchKernelGGL(k_hop_lids_generic, dim3(ge), dim3(kNT), 0, st, sl.p, h);
+        size_t need = 0;
+        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, sl.p.cval, sl.p.out_col[h], (int)E, T,
+                                                               sl.p.out_rowptr[h], sl.p.out_rowptr[h] + 1, 0, 32, st));
+        if (need > sl.cub_tmp_bytes) {
+          SPP_HIP_TRY(hipStreamSynchronize(st));
+          if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
+          sl.cub_tmp = nullptr;
+          SPP_HIP_TRY(hipMalloc(&sl.cub_tmp, need));
+          sl.cub_tmp_bytes = need;
+        }
+        size_t have = sl.cub_tmp_bytes;
+        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sl.cub_tmp, have, sl.p.cval, sl.p.out_col[h], (int)E, T,
+                                                               sl.p.out_rowptr[h], sl.p.out_rowptr[h] + 1, 0, 32, st));
+      }
+    }
+  }
+  SPP_HIP_TRY(hipGetLastError());
+  SPP_HIP_TRY(hipMemcpyAsync(sl.host_state, sl.p.st, sizeof(SlotState), hipMemcpyDeviceToHost, st));
+  SPP_HIP_TRY(hipEventRecord(sl.done, st));
+  sl.sampled = true;
+  sl.waited = false;
+  return SPP_OK;
+}
+
+static void fill_counts(const spp_sampler* s, const SlotState* hs, spp_mfg_counts* out) {
+  const int H = s->cfg.num_hops;
+  out->num_hops = H;
+  out->num_seeds = hs->cnt[0];
+  out->num_nodes = hs->cnt[H];
+  out->draws = hs->dbase[H];
+  for (int k = 0; k < H; ++k) {  // std::reverse(adjs) (fast_sampler.cpp:224)
+    const int h = H - 1 - k;
+    out->T[k] = hs->cnt[h];
+    out->S[k] = hs->cnt[h + 1];
+    out->E[k] = hs->E[h];
+  }
+}
+
+extern "C" spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_counts* out) {
+  SPP_REQUIRE(s && slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_wait: bad sampler/slot");
+  SlotHost& sl = s->slots[slot];
+  if (!sl.sampled) {
+    set_error("spp_sampler_wait: slot %d has no batch in flight", slot);
+    return SPP_ERR_STATE;
+  }
+  SPP_HIP_TRY(hipEventSynchronize(sl.done));
+  sl.waited = true;
+  if (sl.host_state->error) {
+    set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws)",
+              sl.host_state->error);
+    return SPP_ERR_CAPACITY;
+  }
+  if (out) fill_counts(s, sl.host_state, out);
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sampler_export(spp_sampler* s, int32_t slot, const spp_mfg_out* out, void* stream) {
+  SPP_REQUIRE(s && out && slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_export: bad argument");
+  SlotHost& sl = s->slots[slot];
+  if (!sl.sampled || !sl.waited) {
+    set_error("spp_sampler_export: slot %d must be sampled and waited first", slot);
+    return SPP_ERR_STATE;
+  }
+  const SlotState* hs = sl.host_state;
+  const int H = s->cfg.num_hops;
+  ExportSegs g{};
+  int n = 0;
+  int64_t total = 0;
+  auto add = [&](const int32_t* src, int64_t* dst, int64_t len) {
+    if (len <= 0 || dst == nullptr) return;
+    g.src[n] = src;
+    g.dst[n] = dst;
+    g.start[n] = total;
+    total += len;
+    ++n;
+  };
+  add(sl.p.n_ids, out->n_id, hs->cnt[H]);
+  for (int k = 0; k < H; ++k) {
+    const int h = H - 1 - k;
+    add(sl.p.out_rowptr[h], out->rowptr[k], (int64_t)hs->cnt[h] + 1);
+    add(sl.p.out_col[h], out->col[k], hs->E[h]);
+  }
+  g.n = n;
+  g.start[n] = total;
+  if (total == 0) return SPP_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, kNT), 4096);
+  hipLaunchKernelGGL(k_export, dim3(grid), dim3(kNT), 0, as_stream(stream), g);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sampler_gather(spp_sampler* s, int32_t slot, const void* src_dev, int64_t src_rows,
+                                         int64_t row_bytes, int64_t n_rows, void* dst_dev, void* stream) {
+  SPP_REQUIRE(s && slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_gather: bad sampler/slot");
+  SlotHost& sl = s->slots[slot];
+  if (!sl.sampled || !sl.waited) {
+    set_error("spp_sampler_gather: slot %d must be sampled and waited first", slot);
+    return SPP_ERR_STATE;
+  }
+  const int64_t U = sl.host_state->cnt[s->cfg.num_hops];
+  const int64_t n = (n_rows < 0 || n_rows > U) ? U : n_rows;
+  if (n == 0 || row_bytes == 0) return SPP_OK;
+  SPP_REQUIRE(src_dev && dst_dev, "spp_sampler_gather: NULL buffer");
+  (void)src_rows;
+  return gather_rows_i32(src_dev, row_bytes, sl.p.n_ids, n, dst_dev, as_stream(stream));
+}
