@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: sampled-edges/s of the mini-batch data pipeline (neighbour sampling ->
+MFG -> feature/label slice -> PreparedBatch in HBM) on the BASELINE.json config that fits one GPU:
+ogbn-products scale (synthetic, seeded), GraphSAGE fanout [15,10,5], batch 1024, all features in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one batch through the hot path.  N == 1: single-GPU iterator (FastSampler +
+DevicePrefetcher).  N > 1: one process per GPU, replicated topology, features range-partitioned
+N ways with a degree-ranked VIP cache of remote rows, cache-miss rows fetched by RCCL
+all_to_all_single (DeviceDistributedPrefetcher); every rank runs K of its own batches (weak
+scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-products"))
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "8")))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache-frac", type=float, default=0.10)
+    return ap.parse_args()
+
+
+def count_edges(batch) -> int:
+    return sum(int(adj.adj_t.nnz()) for adj in batch.adjs)
+
+
+class EpochFeeder:
+    """Endless stream of device batches: a new FastSampler iterator (epoch) whenever one runs out,
+    with the reference's per-epoch seeded shuffle (fast_trainer/shufflers.py:25-29)."""
+
+    def __init__(self, make_iter, shuffler, get_idx):
+        self.make_iter, self.shuffler, self.get_idx = make_iter, shuffler, get_idx
+        self.epoch = 0
+        self.devit = None
+
+    def _new_epoch(self):
+        self.shuffler.set_epoch(self.epoch)
+        self.devit = self.make_iter(self.get_idx())
+        self.epoch += 1
+
+    def next(self):
+        if self.devit is None:
+            self._new_epoch()
+        while True:
+            try:
+                return next(self.devit)[0]
+            except StopIteration:
+                self._new_epoch()
+
+
+def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
+    """The CPU path timed beside the GPU one on this host's cores, on a bounded sample of the same
+    workload: the compiled reference (oracle/_ref) when it is present, else the oracle port."""
+    import numpy as np
+    rowptr, col, x, y, idx = wl_host
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "fast_sampler.so")
+
+    def run_reference(n_batches):
+        sys.path.insert(0, os.path.dirname(ref_path))
+        import fast_sampler as ref            # the unmodified reference module (built by oracle/build_ref.sh)
+        cfg = ref.Config()
+        cfg.x_cpu, cfg.x_gpu, cfg.y = x, torch.empty(0), y.unsqueeze(-1)
+        cfg.rowptr, cfg.col, cfg.idx = rowptr, col, idx[:n_batches * batch_size].contiguous()
+        cfg.batch_size, cfg.sizes = batch_size, list(sizes)
+        cfg.skip_nonfull_batch, cfg.pin_memory, cfg.distributed = False, False, False
+        cfg.force_exact_num_batches, cfg.exact_num_batches = False, 0
+        cfg.count_remote_frequency, cfg.use_cache = False, False
+        t0 = time.perf_counter()
+        s = ref.Session(threads, 48, cfg)
+        edges = 0
+        nb = 0
+        while True:
+            b = s.blocking_get_batch()
+            if b is None:
+                break
+            edges += sum(int(a[1].numel()) for a in b[2])
+            nb += 1
+        dt = time.perf_counter() - t0
+        del s
+        return edges, nb, dt
+
+    def run_port(n_batches):
+        from oracle import oracle as orc
+        ranges = orc.batch_ranges(n_batches * batch_size, batch_size)
+        st = orc.epoch_run(rowptr.numpy(), col.numpy(), x.numpy(), y.numpy(), idx.numpy(), ranges, sizes, threads)
+        return int(st.sampled_edges), int(st.batches), float(st.seconds)
+
+    kind, run = "port", run_port
+    if os.path.exists(ref_path):
+        try:
+            run_reference(1)
+            kind, run = "reference", run_reference
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] reference module unusable here ({e}); timing the oracle port", file=sys.stderr)
+    probe_batches = max(2, threads)
+    e, nb, dt = run(probe_batches)
+    per_batch = dt / max(nb, 1)
+    n = int(max(probe_batches, min(idx.numel() // batch_size, seconds / max(per_batch, 1e-6))))
+    if n > nb:
+        e, nb, dt = run(n)
+    return {"value": e / dt, "unit": "sampled-edges/s", "cores": threads, "kind": kind,
+            "sample": f"{nb} batches of {batch_size} seeds ({e} sampled edges) in {dt:.2f}s, "
+                      f"{threads} worker threads, incl. feature/label slicing",
+            "batches_per_s": nb / dt}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X data path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+    from salient_plusplus_amd.fast_trainer.shufflers import DistributedShuffler, Shuffler
+    from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher, DevicePrefetcher
+    from salient_plusplus_amd.synthetic import make_workload
+
+    L = nat.load()
+    nat.require_device()
+    t_build = time.perf_counter()
+    wl = make_workload(a.workload, seed=1234, device=dev)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    N, F = wl.num_nodes, wl.x.size(1)
+    sizes, bs = wl.fanouts, wl.batch_size
+    y2 = wl.y.unsqueeze(-1)
+
+    if world == 1:
+        n_train = wl.train_idx.numel()
+        cfg = FastSamplerConfig(
+            x_cpu=wl.x, x_gpu=torch.empty(0), y=y2, rowptr=wl.rowptr, col=wl.col,
+            idx=wl.train_idx, batch_size=bs, sizes=sizes, skip_nonfull_batch=False, pin_memory=False,
+            distributed=False, partition_book=None, cache=fs.Cache(), force_exact_num_batches=True,
+            exact_num_batches=max(1, n_train // bs), count_remote_frequency=False, use_cache=False)
+        sampler = FastSampler(4, a.slots, cfg)
+        shuffler = Shuffler(wl.train_idx)
+
+        def make_iter(idx):
+            sampler.idx = idx
+            return DevicePrefetcher([dev], iter(sampler))
+        feeder = EpochFeeder(make_iter, shuffler, shuffler.get_idx)
+        parallelism = "single"
+        x_local = wl.x
+    else:
+        # contiguous range partition of the features; topology and labels replicated (dataset.py:205-211)
+        offsets = torch.linspace(0, N, world + 1).long()
+        offsets[-1] = N
+        lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+        x_local = wl.x[lo:hi].contiguous()
+        pb = fs.RangePartitionBook(rank, world, offsets)
+        # VIP proxy: the highest-degree remote vertices (cache_strategy "degree"), alpha * N / P rows
+        deg = wl.rowptr[1:] - wl.rowptr[:-1]
+        deg_remote = deg.clone()
+        deg_remote[lo:hi] = -1
+        n_cache = int(a.cache_frac * N / world)
+        cached_vertices = torch.topk(deg_remote, n_cache).indices.sort().values if n_cache > 0 \
+            else torch.empty(0, dtype=torch.int64, device=dev)
+        cache = fs.Cache(rank, world, cached_vertices, wl.x[cached_vertices].contiguous()) if n_cache > 0 \
+            else fs.Cache()
+        # seeds: global seeded shuffle, contiguous slice per rank (shufflers.py:32-45); every rank runs
+        # the same number of batches of `bs` seeds (force_exact_num_batches keeps the all_to_alls aligned)
+        shuffler = DistributedShuffler(wl.train_idx, world)
+        n_local = wl.train_idx.numel() // world
+        cfg = FastSamplerConfig(
+            x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=x_local, y=y2, rowptr=wl.rowptr, col=wl.col,
+            idx=shuffler.get_idx(rank), batch_size=bs, sizes=sizes, skip_nonfull_batch=False, pin_memory=False,
+            distributed=True, partition_book=pb, cache=cache, force_exact_num_batches=True,
+            exact_num_batches=max(1, n_local // bs), count_remote_frequency=False, use_cache=n_cache > 0)
+        sampler = FastSampler(4, a.slots, cfg)
+
+        def make_iter(idx):
+            sampler.idx = idx
+            return DeviceDistributedPrefetcher([dev], iter(sampler), pipeline_on=True)
+        feeder = EpochFeeder(make_iter, shuffler, lambda: shuffler.get_idx(rank))
+        parallelism = f"dp{world}: features range-partitioned {world}-way, VIP(degree) cache " \
+                      f"{a.cache_frac:.0%} of N/P rows, RCCL all_to_all_single"
+
+    # ---- warmup ----
+    for _ in range(a.warmup):
+        feeder.next()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.spp_profile_enable(1)
+    edges = nodes = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        b = feeder.next()
+        edges += count_edges(b)
+        nodes += b.x.size(0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # gather-kernel time, measured live with HIP events on the launching stream
+    ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
+    prof_kind = 0 if world == 1 else 1      # SPP_PROF_GATHER / SPP_PROF_ASSEMBLE
+    nat.check(L.spp_profile_read(prof_kind, C.byref(ms), C.byref(n_launch), C.byref(rows)))
+    L.spp_profile_enable(0)
+
+    stats = torch.tensor([dt, float(edges), float(nodes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, edges, nodes = float(tmax[0]), float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
+        row_bytes = F * 2
+        alg_bytes_per_row = 2 * row_bytes + 8          # read row + write row + int64 index
+        # N == 1: every step launches the x gather and the (tiny) label gather; the label rows are
+        # taken out of the row count, their ~2 us launches stay in the time (conservative).
+        x_rows = rows.value - a.steps * bs if world == 1 else rows.value
+        x_ms = ms.value
+        launches_x = n_launch.value // 2 if world == 1 else n_launch.value
+        achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_gather_rows" if world == 1 else "k_assemble",
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
+                "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
+        out = {
+            "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64/fp16-copy",
+            "data": "synthetic",
+            "config": {"workload": f"{a.workload}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
+                                   f"fanout {sizes}, batch {bs}, all features in HBM",
+                       "parallelism": parallelism, "slots_in_flight": a.slots},
+            "batches_per_s": a.steps * world / dt,
+            "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if world == 1 else None,
+            "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),
+            "graph_build_s": t_build,
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            threads = len(os.sched_getaffinity(0))
+            host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
+            out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

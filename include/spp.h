@@ -46,6 +46,16 @@ const char* spp_last_error(void);
 /* number of visible HIP devices, or <0 when no device / runtime (the product path fails loudly) */
 int spp_device_count(void);
 
+/* Live timing of the HBM-bound kernels with HIP events recorded on the launching stream
+ * (bench.py's roofline leg).  spp_profile_enable(1) clears and starts recording,
+ * spp_profile_read is BLOCKING and returns the summed duration, launch count and processed
+ * units (rows) of one kernel kind. */
+#define SPP_PROF_GATHER 0     /* k_gather_rows   (serial_index)              */
+#define SPP_PROF_ASSEMBLE 1   /* k_assemble      (distributed final assembly) */
+#define SPP_PROF_KINDS 2
+void spp_profile_enable(int on);
+spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
+
 /* ------------------------------------------------------------------------- *
  * a1  std::mt19937 stream (fast_sampler/sample_cpu.hpp:11, seeding
  *     fast_sampler.cpp:994 `gen.seed(range.second*17+5)`): writes raw 32-bit
@@ -88,6 +98,8 @@ typedef struct spp_sampler_cfg {
   int64_t max_batch;           /* max number of seeds in one batch           */
   int32_t num_slots;           /* independent batches that may be in flight  */
   int32_t device;              /* HIP device ordinal                         */
+  int32_t replace;             /* 1: sample WITH replacement (sample_cpu.hpp:74-82; only the free
+                                  sample_adj exposes it, multilayer_sample passes false) */
 } spp_sampler_cfg;
 
 /* counts of one sampled batch; hops in OUTPUT order (outermost first, after the
@@ -113,6 +125,8 @@ spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
 void spp_sampler_destroy(spp_sampler* s);
 /* bytes of HBM workspace held by the sampler (all slots) */
 int64_t spp_sampler_workspace_bytes(const spp_sampler* s);
+/* the configuration the sampler was created with */
+spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out);
 
 /* Enqueue the sampling of one batch into `slot` on `stream`.
  * seeds_dev: int64[n_seeds] in HBM.  The RNG stream is mt19937(rng_seed) with
@@ -203,6 +217,11 @@ typedef struct spp_session_cfg {
   int32_t max_items_in_queue;      /* batches in flight (slots)                */
   int32_t num_streams;             /* HIP streams the slots are spread over (0 = default 4) */
   int32_t device;
+  /* Optional: borrow an existing sampler (same graph, fanouts; max_batch and num_slots at least
+   * what this epoch needs) instead of allocating workspace per epoch -- the counterpart of the
+   * reference's process-global worker pool that outlives Sessions (fast_sampler.cpp:512-513).
+   * A borrowed sampler is not destroyed by spp_session_destroy. */
+  spp_sampler* sampler;
 } spp_session_cfg;
 
 typedef struct spp_batch_desc {

@@ -21,7 +21,7 @@ u32 = C.c_uint32
 class SamplerCfg(C.Structure):
     _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
                 ("num_hops", i32), ("sizes", i64 * SPP_MAX_HOPS), ("max_batch", i64),
-                ("num_slots", i32), ("device", i32)]
+                ("num_slots", i32), ("device", i32), ("replace", i32)]
 
 
 class MfgCounts(C.Structure):
@@ -39,7 +39,7 @@ class SessionCfg(C.Structure):
                 ("idx_dev", p), ("n_idx", i64), ("batch_size", i64), ("num_hops", i32),
                 ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
                 ("force_exact_num_batches", i32), ("exact_num_batches", i64),
-                ("max_items_in_queue", i32), ("num_streams", i32), ("device", i32)]
+                ("max_items_in_queue", i32), ("num_streams", i32), ("device", i32), ("sampler", p)]
 
 
 class BatchDesc(C.Structure):
@@ -52,6 +52,8 @@ SIGNATURES = {
     "spp_abi_version": (C.c_int, []),
     "spp_last_error": (C.c_char_p, []),
     "spp_device_count": (C.c_int, []),
+    "spp_profile_enable": (None, [C.c_int]),
+    "spp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "spp_mt19937_fill": (C.c_int, [u32, i64, i64, p, p]),
     "spp_batch_seed": (u32, [i32]),
     "spp_gather_rows": (C.c_int, [p, i64, i64, p, C.c_int, i64, i64, p, p]),
@@ -59,6 +61,7 @@ SIGNATURES = {
     "spp_sampler_create": (C.c_int, [C.POINTER(SamplerCfg), C.POINTER(p)]),
     "spp_sampler_destroy": (None, [p]),
     "spp_sampler_workspace_bytes": (i64, [p]),
+    "spp_sampler_get_cfg": (C.c_int, [p, C.POINTER(SamplerCfg)]),
     "spp_sampler_sample": (C.c_int, [p, i32, p, i64, u32, i64, p]),
     "spp_sampler_wait": (C.c_int, [p, i32, C.POINTER(MfgCounts)]),
     "spp_sampler_export": (C.c_int, [p, i32, C.POINTER(MfgOut), p]),

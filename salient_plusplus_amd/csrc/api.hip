@@ -3,8 +3,38 @@
 
 #include <cstring>
 
+#include <mutex>
+#include <vector>
+
 namespace spp {
 static thread_local char g_err[1024] = "";
+
+// ---- live kernel timing with HIP events on the launching stream (bench.py roofline) ----
+struct ProfRec {
+  hipEvent_t a, b;
+  int64_t units;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof[SPP_PROF_KINDS];
+
+int prof_begin(int kind, hipStream_t st, int64_t units) {
+  if (!g_prof_on) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof[kind].size() >= (1u << 16)) return -1;
+  ProfRec r{};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  r.units = units;
+  (void)hipEventRecord(r.a, st);
+  g_prof[kind].push_back(r);
+  return (int)g_prof[kind].size() - 1;
+}
+
+void prof_end(int kind, int idx, hipStream_t st) {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < (int)g_prof[kind].size()) (void)hipEventRecord(g_prof[kind][idx].b, st);
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -28,6 +58,37 @@ int spp_device_count(void) {
     return -1;
   }
   return n;
+}
+
+void spp_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(spp::g_prof_mu);
+  for (auto& v : spp::g_prof) {
+    for (auto& r : v) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    v.clear();
+  }
+  spp::g_prof_on = on != 0;
+}
+
+spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units) {
+  SPP_REQUIRE(kind >= 0 && kind < SPP_PROF_KINDS, "spp_profile_read: kind %d out of range", kind);
+  std::lock_guard<std::mutex> lk(spp::g_prof_mu);
+  double ms = 0;
+  int64_t n = 0, u = 0;
+  for (auto& r : spp::g_prof[kind]) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms += t;
+    u += r.units;
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (units) *units = u;
+  return SPP_OK;
 }
 
 // gen.seed(pair.second * 17 + 5)  (reference fast_sampler.cpp:994; pair.second is int32)

@@ -71,6 +71,7 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* 
   if (grid > max_grid) grid = max_grid;
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
+  const int prof = prof_begin(SPP_PROF_GATHER, st, n);
 #define SPP_LAUNCH_GATHER(V)                                                                              \
   hipLaunchKernelGGL((k_gather_rows<V, IdxT>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, idx, n, \
                      row_bytes, chunks, lpr_log2, d)
@@ -82,6 +83,7 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* 
     default: SPP_LAUNCH_GATHER(1); break;
   }
 #undef SPP_LAUNCH_GATHER
+  prof_end(SPP_PROF_GATHER, prof, st);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

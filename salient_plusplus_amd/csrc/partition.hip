@@ -359,6 +359,7 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
   const int gpb = kPT >> lpr_log2;
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(U, gpb), 256 * 32);
   hipStream_t st = as_stream(stream);
+  const int prof = prof_begin(SPP_PROF_ASSEMBLE, st, U);
   switch (vec) {
     case 16: hipLaunchKernelGGL(k_assemble<16>, dim3(grid), dim3(kPT), 0, st, a, chunks, lpr_log2); break;
     case 8: hipLaunchKernelGGL(k_assemble<8>, dim3(grid), dim3(kPT), 0, st, a, chunks, lpr_log2); break;
@@ -366,6 +367,7 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
     case 2: hipLaunchKernelGGL(k_assemble<2>, dim3(grid), dim3(kPT), 0, st, a, chunks, lpr_log2); break;
     default: hipLaunchKernelGGL(k_assemble<1>, dim3(grid), dim3(kPT), 0, st, a, chunks, lpr_log2); break;
   }
+  prof_end(SPP_PROF_ASSEMBLE, prof, st);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -120,14 +120,20 @@ __global__ __launch_bounds__(kNT) void k_seed_init(SlotPtrs s, const int64_t* __
 // ----------------------------------------------------------------------------------------------
 // per-target degree pass
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t& cnt, int32_t& smp) {
+__device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t replace, int32_t& cnt, int32_t& smp) {
+  if (replace && f >= 0) {
+    // with replacement (sample_cpu.hpp:74-82): f draws of gen() % deg whenever deg > 0
+    smp = deg > 0 ? 1 : 0;
+    cnt = smp ? f : 0;
+    return;
+  }
   // sample_cpu.hpp:67-73 (f < 0: all), :91-94 (deg <= f: all), :97-110 (Floyd: f picks)
   smp = (f >= 0 && deg > f) ? 1 : 0;
   cnt = smp ? f : (deg > 0 ? deg : 0);
 }
 
 __global__ __launch_bounds__(kNT) void k_hop_count(SlotPtrs s, const int64_t* __restrict__ rowptr, int32_t h,
-                                                    int32_t f) {
+                                                    int32_t f, int32_t replace) {
   __shared__ int32_t lds[2][kNT / kWave + 1];
   const int32_t T = s.st->cnt[h];
   const int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(kNT) void k_hop_count(SlotPtrs s, const int64_t* __
     const int32_t deg = (int32_t)(re - rs);
     s.deg[i] = deg;
     s.rowstart[i] = rs;
-    target_counts(deg, f, cnt, smp);
+    target_counts(deg, f, replace, cnt, smp);
   }
   int32_t tc, ts;
   block_exclusive_scan<int32_t, kNT>(cnt, lds[0], &tc);
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64) void k_mt_advance(SlotPtrs s, int32_t h, int32_
 // ----------------------------------------------------------------------------------------------
 template <bool kGeneric>
 __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
-                                                   int32_t f) {
+                                                   int32_t f, int32_t replace) {
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, column per lane
   const int32_t T = s.st->cnt[h];
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
   int32_t deg = 0, cnt = 0, smp = 0;
   if (i < T) {
     deg = s.deg[i];
-    target_counts(deg, f, cnt, smp);
+    target_counts(deg, f, replace, cnt, smp);
   }
   int32_t tot;
   const int32_t p0 = s.bsum0[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot);
@@ -279,6 +285,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
     if (smp) {
       int32_t* mine = s.erank + p0;
       for (int32_t k = 0; k < f; ++k) {
+        if (replace) {
+          mine[k] = (int32_t)(rng[k] % (uint32_t)deg);
+          continue;
+        }
         const int32_t j = deg - f + k;
         const int32_t option = (int32_t)(rng[k] % (uint32_t)j);
         bool found = false;
@@ -295,6 +305,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
     // winner = option unless already chosen, then j.
     for (int32_t k = 0; k < f; ++k) {
+      if (replace) {  // sample_cpu.hpp:79-81
+        chosen[k][tid] = (int32_t)(rng[k] % (uint32_t)deg);
+        continue;
+      }
       const int32_t j = deg - f + k;
       const int32_t option = (int32_t)(rng[k] % (uint32_t)j);
       bool found = false;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
 __global__ __launch_bounds__(kNT) void k_hop_expand_generic(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
-                                                             int32_t f) {
+                                                             int32_t f, int32_t replace) {
   const int32_t T = s.st->cnt[h];
   const int32_t E = s.st->E[h];
   const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
@@ -327,7 +341,9 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(SlotPtrs s, const in
   const int32_t i = lo;
   const int32_t deg = s.deg[i];
   const int32_t k = (int32_t)p - rp[i];
-  const int32_t w = (f >= 0 && deg > f) ? s.erank[p] : k;
+  int32_t cnt_, smp_;
+  target_counts(deg, f, replace, cnt_, smp_);
+  const int32_t w = smp_ ? s.erank[p] : k;
   const int32_t c = (int32_t)col[s.rowstart[i] + w];
   s.cval[p] = c;
   s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, (uint32_t)T + (uint32_t)p);
@@ -607,6 +623,12 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
 
 extern "C" int64_t spp_sampler_workspace_bytes(const spp_sampler* s) { return s ? s->bytes : 0; }
 
+extern "C" spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out) {
+  SPP_REQUIRE(s && out, "spp_sampler_get_cfg: NULL argument");
+  *out = s->cfg;
+  return SPP_OK;
+}
+
 static spp_status grow_edge_scratch(spp_sampler* s, SlotHost& sl, int h, int64_t need) {
   // generic path only; the stream has been synchronised by the caller
   if (need > sl.etmp_cap) {
@@ -645,6 +667,7 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
   const int H = s->cfg.num_hops;
   const int64_t* rowptr = s->cfg.rowptr_dev;
   const int64_t* col = s->cfg.col_dev;
+  const int32_t replace = s->cfg.replace ? 1 : 0;
 
   SPP_HIP_TRY(hipMemsetAsync(sl.p.table, 0xFF, sizeof(unsigned long long) * (size_t)s->tab_size, st));
   hipLaunchKernelGGL(k_seed_init, dim3((unsigned)std::max<int64_t>(1, ceil_div(n_seeds, kNT))), dim3(kNT), 0, st, sl.p,
@@ -652,7 +675,7 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
-    hipLaunchKernelGGL(k_hop_count, dim3(gt), dim3(kNT), 0, st, sl.p, rowptr, h, f);
+    hipLaunchKernelGGL(k_hop_count, dim3(gt), dim3(kNT), 0, st, sl.p, rowptr, h, f, replace);
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev = s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(sl.ecap_dyn[h], 0x7fffffff);
     hipLaunchKernelGGL(k_hop_scan, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, ecap_dev);
@@ -660,7 +683,7 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
       hipLaunchKernelGGL(k_mt_advance, dim3(1), dim3(64), 0, st, sl.p, h, f, rng_seed, rng_skip, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f);
+      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f, replace);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path: the edge count is needed on the host to size launches and scratch
@@ -670,8 +693,8 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
       if (sl.host_state->error) break;
       SPP_TRY(grow_edge_scratch(s, sl, h, E));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f);
-      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge), dim3(kNT), 0, st, sl.p, col, h, f);
+      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f, replace);
+      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge), dim3(kNT), 0, st, sl.p, col, h, f, replace);
     }
     hipLaunchKernelGGL(k_hop_flag, dim3(ge), dim3(kNT), 0, st, sl.p, h);
     hipLaunchKernelGGL(k_hop_scan2, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, (int32_t)s->tcap[H]);

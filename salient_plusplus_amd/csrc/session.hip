@@ -21,6 +21,7 @@ using namespace spp;
 struct spp_session {
   spp_session_cfg cfg{};
   spp_sampler* sampler = nullptr;
+  bool owns_sampler = true;
   std::vector<std::pair<int32_t, int32_t>> ranges;
   std::vector<hipStream_t> streams;
   std::vector<hipEvent_t> export_done;  // per slot
@@ -102,20 +103,37 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   const int64_t nb = (int64_t)s->ranges.size();
   s->num_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(cfg->max_items_in_queue, nb));
 
-  spp_sampler_cfg sc{};
-  sc.rowptr_dev = cfg->rowptr_dev;
-  sc.col_dev = cfg->col_dev;
-  sc.num_nodes = cfg->num_nodes;
-  sc.nnz = cfg->nnz;
-  sc.num_hops = cfg->num_hops;
-  for (int h = 0; h < SPP_MAX_HOPS; ++h) sc.sizes[h] = cfg->sizes[h];
-  sc.max_batch = max_batch;
-  sc.num_slots = s->num_slots;
-  sc.device = cfg->device;
-  spp_status rc = spp_sampler_create(&sc, &s->sampler);
-  if (rc != SPP_OK) {
-    delete s;
-    return rc;
+  spp_status rc = SPP_OK;
+  if (cfg->sampler) {
+    spp_sampler_cfg have{};
+    rc = spp_sampler_get_cfg(cfg->sampler, &have);
+    bool ok = rc == SPP_OK && have.rowptr_dev == cfg->rowptr_dev && have.col_dev == cfg->col_dev &&
+              have.num_hops == cfg->num_hops && have.max_batch >= max_batch && have.device == cfg->device && have.replace == 0;
+    for (int h = 0; ok && h < cfg->num_hops; ++h) ok = have.sizes[h] == cfg->sizes[h];
+    if (!ok) {
+      set_error("spp_session_create: borrowed sampler is not compatible with this session's graph/fanouts/batch");
+      delete s;
+      return SPP_ERR_INVALID;
+    }
+    s->sampler = cfg->sampler;
+    s->owns_sampler = false;
+    s->num_slots = std::min<int32_t>(s->num_slots, have.num_slots);
+  } else {
+    spp_sampler_cfg sc{};
+    sc.rowptr_dev = cfg->rowptr_dev;
+    sc.col_dev = cfg->col_dev;
+    sc.num_nodes = cfg->num_nodes;
+    sc.nnz = cfg->nnz;
+    sc.num_hops = cfg->num_hops;
+    for (int h = 0; h < SPP_MAX_HOPS; ++h) sc.sizes[h] = cfg->sizes[h];
+    sc.max_batch = max_batch;
+    sc.num_slots = s->num_slots;
+    sc.device = cfg->device;
+    rc = spp_sampler_create(&sc, &s->sampler);
+    if (rc != SPP_OK) {
+      delete s;
+      return rc;
+    }
   }
   int nstreams = cfg->num_streams > 0 ? cfg->num_streams : 4;
   nstreams = std::min(nstreams, (int)s->num_slots);
@@ -154,7 +172,7 @@ extern "C" void spp_session_destroy(spp_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->cfg.device);
   for (auto st : s->streams) (void)hipStreamSynchronize(st);
-  if (s->sampler) spp_sampler_destroy(s->sampler);
+  if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
   for (auto ev : s->export_done) (void)hipEventDestroy(ev);
   for (auto st : s->streams) (void)hipStreamDestroy(st);
   delete s;

@@ -38,6 +38,10 @@ void set_error(const char* fmt, ...);
     if (s_ != SPP_OK) return s_;   \
   } while (0)
 
+// live event timing (api.hip); kind is one of SPP_PROF_*
+int prof_begin(int kind, hipStream_t st, int64_t units);
+void prof_end(int kind, int idx, hipStream_t st);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1,0 +1,690 @@
+"""Drop-in replacement for SALIENT++'s native ``fast_sampler`` module, backed by the MI355X data
+path (libspp_hip.so, C ABI in include/spp.h).
+
+It exports exactly the surface of the reference pybind module
+(fast_sampler/fast_sampler.cpp:1280-1396): ``Config``, ``Session``, ``ProtoDistributedBatch``,
+``RangePartitionBook``, ``Cache``, ``sample_adj``, ``multilayer_sample``, ``full_sample``,
+``to_row_major``, ``serial_index`` -- same names, argument meaning and error behaviour
+(``RuntimeError`` where the reference has ``TORCH_CHECK``; end of data is ``None``).
+
+Differences that follow from the MI355X design (documented in DESIGN.md):
+  * sampling, MFG construction, slicing and ownership bucketing run on the GPU; every tensor a
+    batch carries lives in HBM (so a later ``.to(device)`` in the transferers is a no-op);
+  * the whole feature matrix of the rank is HBM resident (288 GB): ``x_cpu`` is uploaded once,
+    ``sliced_cpu_features`` is always empty and ``async_slice_tensors`` degenerates;
+  * ``num_threads`` selects HIP streams instead of CPU worker threads, and
+    ``max_items_in_queue`` bounds the batch slots in flight.
+There is no CPU fallback: without the HIP extension and a GPU every entry point raises.
+"""
+import ctypes as C
+import datetime
+import os
+import threading
+from typing import List, Optional, Sequence
+
+import torch
+
+from .. import _native as nat
+
+__all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
+           "multilayer_sample", "full_sample", "to_row_major", "serial_index"]
+
+_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "8"))
+
+
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+def _lib():
+    L = nat.load()
+    nat.require_device()
+    return L
+
+
+def _device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+class _ResidentCache:
+    """HBM residency of the (large, epoch-invariant) host tensors a Config carries.
+
+    The reference shares the CPU tensors of a Config between Sessions; here the graph and the
+    features are uploaded once and stay in HBM for every later Session (keyed by storage identity)."""
+
+    def __init__(self):
+        self._d = {}
+        self._lock = threading.Lock()
+
+    def get(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
+        dev = _device()
+        if t.is_cuda:
+            r = t if t.device == dev else t.to(dev)
+            r = r.contiguous()
+            return r if dtype is None or r.dtype == dtype else r.to(dtype)
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, dtype, dev.index)
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is not None and hit[0] is t:
+                return hit[1]
+            src = t.contiguous()
+            if dtype is not None and src.dtype != dtype:
+                src = src.to(dtype)
+            r = src.to(dev)
+            self._d[key] = (t, r)          # keep `t` alive so the key cannot be recycled
+            return r
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+
+
+_resident = _ResidentCache()
+
+
+def clear_resident_cache():
+    """Drop every HBM copy made for host tensors (graph, features) and every pooled sampler."""
+    _resident.clear()
+    _SamplerPool.clear()
+
+
+def _as_i64_list(sizes: Sequence[int]) -> List[int]:
+    out = [int(s) for s in sizes]
+    if not 1 <= len(out) <= nat.SPP_MAX_HOPS:
+        raise RuntimeError(f"sizes must have between 1 and {nat.SPP_MAX_HOPS} entries, got {len(out)}")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# RangePartitionBook / Cache   (fast_sampler/range_partition_book.{hpp,cpp})
+# --------------------------------------------------------------------------------------------
+class RangePartitionBook:
+    """``RangePartitionBook(rank, world_size, partition_offsets)`` (range_partition_book.hpp:31-57)."""
+
+    def __init__(self, rank: int = 0, world_size: int = 1, partition_offsets: Optional[torch.Tensor] = None):
+        self.rank = int(rank)
+        self.world_size = int(world_size)
+        self.partition_offsets = partition_offsets if partition_offsets is not None \
+            else torch.zeros(0, dtype=torch.int64)
+
+    def _offsets_host(self):
+        offs = self.partition_offsets.detach().to("cpu", torch.int64).contiguous()
+        if offs.numel() < 2 or offs.numel() > nat.SPP_MAX_PARTS + 1:
+            raise RuntimeError(f"partition_offsets must hold 2..{nat.SPP_MAX_PARTS + 1} entries")
+        return offs
+
+    def nid2localnid(self, nids: torch.Tensor, partition_idx: int) -> torch.Tensor:
+        # nids - partition_offsets[partition_idx]   (range_partition_book.cpp:95-96)
+        return nids - self.partition_offsets[partition_idx].to(nids.device)
+
+    def nid2partid(self, nids: torch.Tensor) -> torch.Tensor:
+        # searchsorted(partition_offsets, nids, right=True) - 1   (range_partition_book.cpp:98-100)
+        if nids.is_cuda:
+            offs = self._offsets_host()
+            src = nids.contiguous().to(torch.int64)
+            out = torch.empty_like(src)
+            nat.check(_lib().spp_nid2partid(C.c_void_p(offs.data_ptr()), offs.numel(), _ptr(src), src.numel(),
+                                            _ptr(out), _stream_ptr()))
+            return out
+        # host tensors are handled by the same ATen op the reference calls
+        return torch.searchsorted(self.partition_offsets.to(nids.device), nids, right=True) - 1
+
+    def nid_is_local(self, nids: torch.Tensor) -> torch.Tensor:
+        lo = self.partition_offsets[self.rank].to(nids.device)
+        hi = self.partition_offsets[self.rank + 1].to(nids.device)
+        return (nids >= lo) * (nids < hi)       # range_partition_book.cpp:105-107
+
+    def partid2nids(self, partition_idx: int) -> torch.Tensor:
+        return torch.arange(int(self.partition_offsets[partition_idx]),
+                            int(self.partition_offsets[partition_idx + 1]), dtype=torch.int64)
+
+
+class Cache:
+    """``Cache()`` / ``Cache(rank, world_size, cached_vertices, cached_features)``
+    (range_partition_book.hpp:60-91).  The reference's two dense 2e8-entry host tables become one
+    device-resident direct map ``int32[max_id+1]`` (-1 = not cached), built by spp_cache_build_map."""
+
+    def __init__(self, rank: int = 0, world_size: int = 0, cached_vertices: Optional[torch.Tensor] = None,
+                 cached_features: Optional[torch.Tensor] = None):
+        self.rank = int(rank)
+        self.world_size = int(world_size)
+        # default ctor: empty tensors, not None (range_partition_book.cpp:116-119)
+        self.cached_vertices = cached_vertices if cached_vertices is not None \
+            else torch.empty(0, dtype=torch.int64)
+        self.cached_features = cached_features if cached_features is not None \
+            else torch.empty((0, 0), dtype=torch.float16)
+        self._map = None
+        self._vertices_dev = None
+        self._features_dev = None
+
+    # -- device side state, built lazily (needs a GPU) --
+    def device_map(self) -> torch.Tensor:
+        if self._map is None:
+            L = _lib()
+            cv = self.cached_vertices.to(_device(), torch.int64).contiguous()
+            n = int(cv.max().item()) + 1 if cv.numel() > 0 else 1
+            m = torch.empty(n, dtype=torch.int32, device=_device())
+            nat.check(L.spp_cache_build_map(_ptr(cv), cv.numel(), _ptr(m), n, _stream_ptr()))
+            self._vertices_dev = cv
+            self._map = m
+        return self._map
+
+    def device_features(self) -> torch.Tensor:
+        if self._features_dev is None:
+            self._features_dev = self.cached_features.to(_device()).contiguous()
+        return self._features_dev
+
+    def _lookup(self, nids: torch.Tensor, want_flag: bool):
+        L = _lib()
+        m = self.device_map()
+        src = nids.to(_device(), torch.int64).contiguous()
+        flag = torch.empty(src.numel(), dtype=torch.bool, device=src.device) if want_flag else None
+        cid = None if want_flag else torch.empty(src.numel(), dtype=torch.int64, device=src.device)
+        nat.check(L.spp_cache_lookup(_ptr(m), m.numel(), _ptr(src), src.numel(), _ptr(flag), _ptr(cid),
+                                     _stream_ptr()))
+        out = flag if want_flag else cid
+        return out if nids.is_cuda else out.cpu()
+
+    def nid_is_cached(self, nids: torch.Tensor) -> torch.Tensor:
+        return self._lookup(nids, True)        # range_partition_book.cpp:161-183
+
+    def nid2cachenid(self, nids: torch.Tensor) -> torch.Tensor:
+        return self._lookup(nids, False)       # range_partition_book.cpp:185-195
+
+
+# --------------------------------------------------------------------------------------------
+# Config / ProtoDistributedBatch   (fast_sampler.cpp:515-531, :180-188)
+# --------------------------------------------------------------------------------------------
+class Config:
+    """Default-constructible record with the read/write fields of fast_sampler.cpp:1290-1309."""
+
+    def __init__(self):
+        self.x_cpu = torch.empty(0)
+        self.x_gpu = torch.empty(0)
+        self.y = None
+        self.rowptr = torch.empty(0, dtype=torch.int64)
+        self.col = torch.empty(0, dtype=torch.int64)
+        self.idx = torch.empty(0, dtype=torch.int64)
+        self.batch_size = 0
+        self.sizes = []
+        self.skip_nonfull_batch = False
+        self.pin_memory = False
+        self.distributed = False
+        self.partition_book = RangePartitionBook()
+        self.cache = Cache()
+        self.force_exact_num_batches = False
+        self.exact_num_batches = 0
+        self.count_remote_frequency = False
+        self.use_cache = False
+
+
+class ProtoDistributedBatch:
+    """Batch record of the distributed worker branch (fast_sampler.cpp:180-188)."""
+
+    def __init__(self):
+        self.partition_nids = []
+        self.sliced_cpu_features = None
+        self.sliced_cpu_labels = None
+        self.cached_nids = None
+        self.perm_partition_to_mfg = None
+        self.adjs = []
+        self.idx_range = (0, 0)
+        # extras of the GPU path (ignored by reference-style consumers)
+        self.n_id = None
+
+
+# --------------------------------------------------------------------------------------------
+# sampler pool: workspace outlives Sessions like the reference's global thread pool
+# (fast_sampler.cpp:512-513)
+# --------------------------------------------------------------------------------------------
+class _SamplerPool:
+    _pool = {}
+    _lock = threading.Lock()
+
+    @classmethod
+    def acquire(cls, rowptr_d, col_d, sizes, max_batch, slots, device, replace=False):
+        key = (rowptr_d.data_ptr(), col_d.data_ptr(), tuple(sizes), device, bool(replace))
+        with cls._lock:
+            lst = cls._pool.setdefault(key, [])
+            for i, (h, mb, ns, keep) in enumerate(lst):
+                if mb >= max_batch and ns >= slots:
+                    return lst.pop(i)
+        L = _lib()
+        cfg = nat.SamplerCfg()
+        cfg.rowptr_dev, cfg.col_dev = rowptr_d.data_ptr(), col_d.data_ptr()
+        cfg.num_nodes, cfg.nnz = rowptr_d.numel() - 1, col_d.numel()
+        cfg.num_hops = len(sizes)
+        for i, s in enumerate(sizes):
+            cfg.sizes[i] = s
+        cfg.max_batch, cfg.num_slots, cfg.device = max_batch, slots, device
+        cfg.replace = int(bool(replace))
+        h = C.c_void_p()
+        nat.check(L.spp_sampler_create(C.byref(cfg), C.byref(h)))
+        return (h, max_batch, slots, (rowptr_d, col_d))
+
+    @classmethod
+    def release(cls, key_tensors, sizes, device, entry, replace=False):
+        key = (key_tensors[0].data_ptr(), key_tensors[1].data_ptr(), tuple(sizes), device, bool(replace))
+        with cls._lock:
+            cls._pool.setdefault(key, []).append(entry)
+
+    @classmethod
+    def clear(cls):
+        with cls._lock:
+            L = nat.load()
+            for lst in cls._pool.values():
+                for (h, _mb, _ns, _keep) in lst:
+                    L.spp_sampler_destroy(h)
+            cls._pool.clear()
+
+
+def _host_ranges(n, batch_size, skip_nonfull, force_exact, exact_k):
+    """fast_sampler.cpp:587-627 (only used to size the pooled sampler before the native session exists)."""
+    if force_exact:
+        if exact_k <= 0:
+            return 0, 1
+        avg = n // exact_k - 1
+        rem = n - avg * exact_k
+        return exact_k, max(1, avg + (rem + exact_k - 1) // exact_k)
+    nb, r = divmod(n, batch_size)
+    if r and not skip_nonfull:
+        nb += 1
+    return nb, max(1, min(batch_size, n))
+
+
+# --------------------------------------------------------------------------------------------
+# Session   (fast_sampler.cpp:533-936 + worker :963-1274)
+# --------------------------------------------------------------------------------------------
+class Session:
+    def __init__(self, num_threads: int, max_items_in_queue: int, config: Config):
+        L = _lib()
+        if max_items_in_queue <= 0:
+            raise RuntimeError(f"max_items_in_queue ({max_items_in_queue}) must be positive")
+        self.config = config
+        self._L = L
+        self._h = None
+        self._dev = _device()
+        self._sizes = _as_i64_list(config.sizes)
+        self._rowptr = _resident.get(config.rowptr, torch.int64)
+        self._col = _resident.get(config.col, torch.int64)
+        self._idx = config.idx.to(self._dev, torch.int64).contiguous()
+        self._distributed = bool(config.distributed)
+
+        # features / labels resident in HBM
+        if self._distributed:
+            xg, xc = config.x_gpu, config.x_cpu
+            parts = [t for t in (xg, xc) if t is not None and t.dim() == 2 and t.size(0) > 0]
+            if len(parts) == 2:
+                self._x = _resident_concat(xg, xc)
+            elif len(parts) == 1:
+                self._x = _resident.get(parts[0])
+            else:
+                self._x = None
+        else:
+            self._x = _resident.get(config.x_cpu) if config.x_cpu is not None and config.x_cpu.numel() > 0 else None
+        if self._x is not None and not (self._x.dim() == 2 and self._x.stride(-1) == 1):
+            raise RuntimeError("input must be 2D row-major tensor")
+        y = config.y
+        self._y = _resident.get(y) if y is not None and y.numel() > 0 else None
+        if self._y is not None and self._y.dim() == 1:
+            self._y = self._y.unsqueeze(-1)
+
+        n = self._idx.numel()
+        force_exact = bool(config.force_exact_num_batches)
+        if force_exact and (config.exact_num_batches <= 0 or n // max(1, config.exact_num_batches) < 1):
+            raise RuntimeError("force_exact_num_batches needs idx.numel() / exact_num_batches >= 1")
+        nb, max_batch = _host_ranges(n, int(config.batch_size), bool(config.skip_nonfull_batch), force_exact,
+                                     int(config.exact_num_batches))
+        slots = max(1, min(int(max_items_in_queue), _MAX_SLOTS, max(nb, 1)))
+        self._pool_entry = _SamplerPool.acquire(self._rowptr, self._col, self._sizes, max_batch, slots,
+                                                self._dev.index)
+
+        cfg = nat.SessionCfg()
+        cfg.rowptr_dev, cfg.col_dev = self._rowptr.data_ptr(), self._col.data_ptr()
+        cfg.num_nodes, cfg.nnz = self._rowptr.numel() - 1, self._col.numel()
+        cfg.idx_dev, cfg.n_idx = (self._idx.data_ptr() if n > 0 else None), n
+        cfg.batch_size = int(config.batch_size)
+        cfg.num_hops = len(self._sizes)
+        for i, s in enumerate(self._sizes):
+            cfg.sizes[i] = s
+        cfg.skip_nonfull_batch = int(bool(config.skip_nonfull_batch))
+        cfg.force_exact_num_batches = int(force_exact)
+        cfg.exact_num_batches = int(config.exact_num_batches)
+        cfg.max_items_in_queue = slots
+        cfg.num_streams = max(1, min(int(num_threads), 4))
+        cfg.device = self._dev.index
+        cfg.sampler = self._pool_entry[0]
+        h = C.c_void_p()
+        try:
+            nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
+        except Exception:
+            _SamplerPool.release((self._rowptr, self._col), self._sizes, self._dev.index, self._pool_entry)
+            self._pool_entry = None
+            raise
+        self._h = h
+        self._desc = nat.BatchDesc()
+        self._part_ws = None
+        self._slice_result = []
+        # remote-frequency statistics (count_remote_frequency, fast_sampler.cpp:1093-1103 / :835-880)
+        self._freq = None
+        self.remote_frequency_tensor = torch.empty(0, dtype=torch.int64)
+        self.remote_vertices_ordered_by_freq = torch.empty(0, dtype=torch.int64)
+        self._freq_reduced = False
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._L.spp_session_destroy(self._h)
+            self._h = None
+        if getattr(self, "_pool_entry", None) is not None:
+            _SamplerPool.release((self._rowptr, self._col), self._sizes, self._dev.index, self._pool_entry)
+            self._pool_entry = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- properties of fast_sampler.cpp:1325-1338 ----
+    @property
+    def num_total_batches(self) -> int:
+        return int(self._L.spp_session_num_total_batches(self._h))
+
+    @property
+    def num_consumed_batches(self) -> int:
+        return int(self._L.spp_session_num_consumed_batches(self._h))
+
+    @property
+    def approx_num_complete_batches(self) -> int:
+        return self.num_consumed_batches
+
+    @property
+    def total_blocked_dur(self) -> datetime.timedelta:
+        return datetime.timedelta(microseconds=int(self._L.spp_session_blocked_us(self._h)))
+
+    @property
+    def total_blocked_occasions(self) -> int:
+        return int(self._L.spp_session_blocked_occasions(self._h))
+
+    # ---- batch production ----
+    def _next_desc(self):
+        rc = self._L.spp_session_next(self._h, C.byref(self._desc))
+        nat.check(rc)
+        return rc == 1
+
+    def _alloc_mfg(self, counts, want_n_id=True):
+        dev = self._dev
+        out = nat.MfgOut()
+        n_id = None
+        if want_n_id:
+            n_id = torch.empty(counts.num_nodes, dtype=torch.int64, device=dev)
+            out.n_id = n_id.data_ptr() if n_id.numel() else None
+        adjs = []
+        e_id = torch.empty(0, dtype=torch.int64, device=dev)          # sample_cpu.hpp:120: always empty
+        for k in range(counts.num_hops):
+            rp = torch.empty(counts.T[k] + 1, dtype=torch.int64, device=dev)
+            cl = torch.empty(counts.E[k], dtype=torch.int64, device=dev)
+            out.rowptr[k] = rp.data_ptr()
+            out.col[k] = cl.data_ptr() if cl.numel() else None
+            adjs.append((rp, cl, e_id, (int(counts.T[k]), int(counts.S[k]))))
+        return out, n_id, adjs
+
+    def blocking_get_batch(self):
+        """-> None or (x, y-or-None, [(rowptr, col, e_id, (T, S)) ...], (start, stop))
+        (worker non-distributed branch, fast_sampler.cpp:1004-1016)."""
+        if not self._next_desc():
+            return None
+        d = self._desc
+        c = d.counts
+        out, _n_id, adjs = self._alloc_mfg(c, want_n_id=False)         # n_id is not part of the tuple
+        x = y = None
+        if self._x is not None:
+            x = torch.empty((c.num_nodes, self._x.size(1)), dtype=self._x.dtype, device=self._dev)
+        else:
+            x = torch.empty((c.num_nodes, 0), device=self._dev)
+        if self._y is not None:
+            y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
+        self._export(out, x, y)
+        return (x, y, adjs, (int(d.start), int(d.stop)))
+
+    try_get_batch = blocking_get_batch
+
+    def _export(self, out, x, y):
+        xs, ys = self._x, self._y
+        nat.check(self._L.spp_session_export(
+            self._h, C.byref(out),
+            _ptr(xs) if x is not None and xs is not None else None, xs.size(0) if xs is not None else 0,
+            xs.size(1) * xs.element_size() if xs is not None else 0, _ptr(x) if xs is not None else None,
+            _ptr(ys) if y is not None and ys is not None else None, ys.size(0) if ys is not None else 0,
+            ys.size(1) * ys.element_size() if ys is not None else 0, _ptr(y) if ys is not None else None,
+            _stream_ptr()))
+
+    def blocking_get_batch_distributed(self):
+        """-> None or ProtoDistributedBatch (worker distributed branch, fast_sampler.cpp:1017-1272)."""
+        if not self._next_desc():
+            return None
+        d = self._desc
+        c = d.counts
+        cfg = self.config
+        pb = cfg.partition_book
+        P, rank = int(pb.world_size), int(pb.rank)
+        out, n_id, adjs = self._alloc_mfg(c)
+        y = None
+        if self._y is not None:
+            y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
+        self._export(out, None, y)
+        U = int(c.num_nodes)
+        L = self._L
+        offs = pb._offsets_host()
+        use_cache = bool(cfg.use_cache)
+        cmap = cfg.cache.device_map() if use_cache else None
+        parts = torch.empty(U, dtype=torch.int64, device=self._dev)
+        cached = torch.empty(U, dtype=torch.int64, device=self._dev)
+        perm = torch.empty(U, dtype=torch.int64, device=self._dev)
+        counts = torch.empty(P + 2, dtype=torch.int64, device=self._dev)
+        need = int(L.spp_partition_workspace_bytes(max(U, 1)))
+        if self._part_ws is None or self._part_ws.numel() < need:
+            self._part_ws = torch.empty(need, dtype=torch.uint8, device=self._dev)
+        x_rows = self._x.size(0) if self._x is not None else 0
+        nat.check(L.spp_partition_batch(_ptr(n_id), U, C.c_void_p(offs.data_ptr()), P, rank, int(use_cache),
+                                        _ptr(cmap), cmap.numel() if cmap is not None else 0, x_rows,
+                                        _ptr(parts), _ptr(cached), _ptr(perm), C.c_void_p(counts.data_ptr()),
+                                        None, C.c_void_p(self._part_ws.data_ptr()), self._part_ws.numel(),
+                                        _stream_ptr()))
+        cnt = counts.cpu().tolist()            # sizes are needed on the host to slice the views
+        b = ProtoDistributedBatch()
+        bounds = [0]
+        for m in range(P):
+            bounds.append(bounds[-1] + int(cnt[m]))
+        b.partition_nids = [parts[bounds[m]:bounds[m + 1]] for m in range(P)]
+        b.cached_nids = cached[:int(cnt[P])]
+        b.perm_partition_to_mfg = perm
+        feat_dim = self._x.size(1) if self._x is not None else 0
+        feat_dtype = self._x.dtype if self._x is not None else torch.float16
+        b.sliced_cpu_features = torch.empty((0, feat_dim), dtype=feat_dtype)   # all local rows are in HBM
+        b.sliced_cpu_labels = y if y is not None else torch.zeros(0)
+        b.adjs = adjs
+        b.idx_range = (int(d.start), int(d.stop))
+        b.n_id = n_id
+        if cfg.count_remote_frequency and not use_cache:
+            self._count_remote(b.partition_nids, rank)
+        return b
+
+    try_get_batch_distributed = blocking_get_batch_distributed
+
+    # ---- host-memory slicing for peers (fast_sampler.cpp:716-775): nothing lives in host memory ----
+    def async_slice_tensors(self, ids: List[torch.Tensor], my_rank: int):
+        res = []
+        for t in ids:
+            n = t.numel()
+            pos = torch.arange(n, dtype=torch.int64)
+            neg = t.cpu() < 0 if n else torch.zeros(0, dtype=torch.bool)
+            res.append([torch.empty(0, dtype=torch.int64), pos[~neg], pos[neg]])
+        self._slice_result = res
+
+    def wait_slice_tensors(self):
+        return None
+
+    def get_slice_tensors(self):
+        return self._slice_result
+
+    # ---- remote frequency counting (simulation cache strategy) ----
+    def _count_remote(self, partition_nids, rank):
+        n = self._rowptr.numel() - 1
+        if self._freq is None:
+            self._freq = torch.zeros(n, dtype=torch.int64, device=self._dev)
+        for m, t in enumerate(partition_nids):
+            if m != rank and t.numel():
+                self._freq.index_add_(0, t, torch.ones_like(t))
+
+    def reduce_multithreaded_frequency_counts(self):
+        if self._freq_reduced:
+            return
+        if self._freq is not None:
+            nz = self._freq.nonzero().view(-1)
+            f = self._freq[nz]
+            order = torch.argsort(f, descending=True, stable=True)
+            self.remote_frequency_tensor = f[order].cpu()
+            self.remote_vertices_ordered_by_freq = nz[order].cpu()
+        self._freq_reduced = True
+
+    def get_n_most_freq_remote_vertices(self, n: int) -> torch.Tensor:
+        self.reduce_multithreaded_frequency_counts()
+        return self.remote_vertices_ordered_by_freq[:n].clone()
+
+
+def _resident_concat(x_gpu: torch.Tensor, x_cpu: torch.Tensor) -> torch.Tensor:
+    """All local feature rows in one HBM tensor: rows [0, |x_gpu|) then the former host rows."""
+    key_t = x_cpu
+    dev = _device()
+    key = ("cat", x_gpu.data_ptr(), x_cpu.data_ptr(), tuple(x_gpu.shape), tuple(x_cpu.shape), dev.index)
+    with _resident._lock:
+        hit = _resident._d.get(key)
+        if hit is not None and hit[0] is key_t:
+            return hit[1]
+        r = torch.cat([x_gpu.to(dev), x_cpu.to(dev)], dim=0).contiguous()
+        _resident._d[key] = (key_t, r)
+        return r
+
+
+# --------------------------------------------------------------------------------------------
+# free functions   (fast_sampler.cpp:1339-1366)
+# --------------------------------------------------------------------------------------------
+class _ThreadGen(threading.local):
+    """`thread_local std::mt19937 gen` of the calling thread (sample_cpu.hpp:11): default-seeded
+    (5489) and never re-seeded by the free functions, so its position carries over between calls."""
+
+    def __init__(self):
+        self.seed = 5489
+        self.pos = 0
+
+
+_gen = _ThreadGen()
+
+
+def _sample_once(rowptr, col, idx, sizes, replace=False):
+    L = _lib()
+    dev = _device()
+    sizes = _as_i64_list(sizes)
+    rowptr_d = _resident.get(rowptr, torch.int64)
+    col_d = _resident.get(col, torch.int64)
+    idx_d = idx.to(dev, torch.int64).contiguous()
+    entry = _SamplerPool.acquire(rowptr_d, col_d, sizes, max(1, idx_d.numel()), 1, dev.index, replace)
+    try:
+        h = entry[0]
+        st = _stream_ptr()
+        nat.check(L.spp_sampler_sample(h, 0, _ptr(idx_d), idx_d.numel(), _gen.seed, _gen.pos, st))
+        cnt = nat.MfgCounts()
+        nat.check(L.spp_sampler_wait(h, 0, C.byref(cnt)))
+        _gen.pos += int(cnt.draws)
+        out = nat.MfgOut()
+        n_id = torch.empty(cnt.num_nodes, dtype=torch.int64, device=dev)
+        out.n_id = n_id.data_ptr() if n_id.numel() else None
+        adjs = []
+        e_id = torch.empty(0, dtype=torch.int64, device=dev)
+        for k in range(cnt.num_hops):
+            rp = torch.empty(cnt.T[k] + 1, dtype=torch.int64, device=dev)
+            cl = torch.empty(cnt.E[k], dtype=torch.int64, device=dev)
+            out.rowptr[k] = rp.data_ptr()
+            out.col[k] = cl.data_ptr() if cl.numel() else None
+            adjs.append((rp, cl, e_id, (int(cnt.T[k]), int(cnt.S[k]))))
+        nat.check(L.spp_sampler_export(h, 0, C.byref(out), st))
+        torch.cuda.current_stream().synchronize()
+    finally:
+        _SamplerPool.release((rowptr_d, col_d), sizes, dev.index, entry, replace)
+    return n_id, adjs
+
+
+def sample_adj(rowptr, col, idx, num_neighbors: int, replace: bool, pin_memory: bool = False):
+    """-> (rowptr, col, n_id, e_id); n_id is int32 like the reference's tensor overload
+    (sample_cpu.hpp:154-165)."""
+    n_id, adjs = _sample_once(rowptr, col, idx, [int(num_neighbors)], replace)
+    rp, cl, e_id, _ = adjs[0]
+    return rp, cl, n_id.to(torch.int32), e_id
+
+
+def multilayer_sample(idx, sizes, rowptr, col, pin_memory: bool = False):
+    """-> (n_id int64, [(rowptr, col, e_id, (T, S)) ...] outermost hop first) (fast_sampler.cpp:229-236)."""
+    return _sample_once(rowptr, col, idx, sizes, False)
+
+
+def full_sample(x, y, rowptr, col, idx, batch_size, sizes, skip_nonfull_batch=False, pin_memory=False):
+    """Pre-sampler of fast_sampler.cpp:310-366: every batch of `idx`, as one list (the reference
+    returns one list per OpenMP thread; callers chain them)."""
+    cfg = Config()
+    cfg.x_cpu, cfg.y, cfg.rowptr, cfg.col, cfg.idx = x, y, rowptr, col, idx
+    cfg.batch_size, cfg.sizes, cfg.skip_nonfull_batch = int(batch_size), list(sizes), bool(skip_nonfull_batch)
+    s = Session(1, _MAX_SLOTS, cfg)
+    out = []
+    try:
+        while True:
+            b = s.blocking_get_batch()
+            if b is None:
+                break
+            out.append(b)
+    finally:
+        s.close()
+    return [out]
+
+
+def to_row_major(t: torch.Tensor) -> torch.Tensor:
+    """fast_sampler.cpp:281-308."""
+    if t.dim() != 2:
+        raise RuntimeError("only support 2D tensors")
+    tr, tc = t.size(0), t.size(1)
+    if t.stride(0) == tc and t.stride(1) == 1:
+        return t                               # already row major
+    if not (t.stride(0) == 1 and t.stride(1) == tr):
+        raise RuntimeError("input has unrecognizable stides")
+    L = _lib()
+    storage = t.t().to(_device())              # the column-major storage, viewed as contiguous [tc, tr]
+    assert storage.is_contiguous()
+    out = torch.empty((tr, tc), dtype=t.dtype, device=_device())
+    nat.check(L.spp_to_row_major(_ptr(storage), tr, tc, t.element_size(), _ptr(out), _stream_ptr()))
+    return out if t.is_cuda else out.cpu()
+
+
+def serial_index(inp: torch.Tensor, idx: torch.Tensor, n=None, pin_memory: bool = False) -> torch.Tensor:
+    """out[i,:] = in[idx[i],:] (fast_sampler.cpp:238-279); `n` limits/sets the output rows."""
+    if isinstance(n, bool):                    # serial_index(in, idx, pin_memory) overload
+        n, pin_memory = None, n
+    if not ((inp.dim() == 2 and inp.stride(-1) == 1) or inp.size(-1) == 1):
+        raise RuntimeError("input must be 2D row-major tensor")
+    L = _lib()
+    src = _resident.get(inp)
+    ind = idx.to(_device(), torch.int64).contiguous()
+    n_out = ind.numel() if n is None else int(n)
+    f = inp.size(-1)
+    out = torch.empty((n_out, f), dtype=inp.dtype, device=_device())
+    nat.check(L.spp_gather_rows(_ptr(src), src.size(0), f * src.element_size(), _ptr(ind), 8, ind.numel(), n_out,
+                                _ptr(out), _stream_ptr()))
+    return out

@@ -1,0 +1,320 @@
+"""Device iterators: same protocol as the reference's fast_trainer/transferers.py
+(``DeviceIterator`` :20-29, ``DevicePrefetcher`` :890-970, ``DeviceTransferer`` :973-985,
+``DeviceDistributedPrefetcher`` :33-887) -- ctor ``(devices, it, pipeline_on=True)``, attributes
+``devices`` / ``device`` / ``it``, ``__next__() -> [PreparedBatch]`` raising ``StopIteration`` after
+a device synchronise, ``print_stats()``, ``NUMBER_OF_SENT_BYTES``.
+
+MI355X re-design of the distributed iterator.  The reference runs a 10-stage pipeline with three
+list-form NCCL all_to_alls, two forced D2H syncs, host-side slicing of host-resident rows and a
+zeros+scatter+cat+permute assembly (~4x the algorithmic feature bytes).  Here every feature row of
+the rank is HBM resident, the sampler already produced the ownership buckets on the GPU, and a batch
+needs only:
+
+   B  counts  : one all_to_all_single of P int64 (split sizes for the next two exchanges)
+   C  ids     : one all_to_all_single of the requested node ids (variable splits)
+   D  serve   : one row gather  x_local[ids - offset]  straight into the send buffer
+   E  rows    : one all_to_all_single of feature rows over xGMI (own slot empty)
+   F  assemble: one fused kernel writing x in MFG order from {local rows, cache rows, received rows}
+
+The stages of consecutive batches are software-pipelined (newest stage first, like
+transferers.py:399-421) on one side stream, so the only host wait -- reading the P received counts --
+is on a collective issued one iteration earlier.
+"""
+import ctypes as C
+import time
+from collections import deque
+from typing import Iterator, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .samplers import PreparedBatch, ProtoBatch, ProtoDistributedBatch
+from .utils import runtime_stats_cuda
+
+
+class DeviceIterator(Iterator[List[PreparedBatch]]):
+    """Abstract iterator returning one PreparedBatch per device (transferers.py:20-29)."""
+    devices: List[torch.device]
+
+    def __init__(self, devices):
+        assert len(devices) > 0
+        self.devices = devices
+        self.device = self.devices[0]
+
+    def print_stats(self):
+        return
+
+
+def _is_cuda(device) -> bool:
+    return torch.device(device).type == "cuda"
+
+
+class _HipFeatureOps:
+    """Feature movement of the distributed iterator on the HIP kernels (product path)."""
+
+    def __init__(self):
+        from .. import _native as nat
+        self.nat = nat
+        self.L = nat.load()
+        nat.require_device()
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def gather_rows(self, x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((idx.numel(), x.size(1)), dtype=x.dtype, device=x.device)
+        self.nat.check(self.L.spp_gather_rows(self._p(x), x.size(0), x.size(1) * x.element_size(), self._p(idx), 8,
+                                              idx.numel(), idx.numel(), self._p(out), self._stream()))
+        return out
+
+    def assemble(self, n_id, perm, seg_start: List[int], P: int, rank: int, rank_offset: int, x_local, recv,
+                 cache_feats, cached_nids) -> torch.Tensor:
+        U = n_id.numel()
+        out = torch.empty((U, x_local.size(1)), dtype=x_local.dtype, device=x_local.device)
+        seg = (C.c_int64 * (P + 2))(*seg_start)
+        self.nat.check(self.L.spp_assemble_features(
+            self._p(n_id), self._p(perm), U, seg, P, rank, rank_offset, self._p(x_local), x_local.size(0),
+            self._p(recv), self._p(cache_feats), self._p(cached_nids), x_local.size(1) * x_local.element_size(),
+            self._p(out), self._stream()))
+        return out
+
+
+class _SideStream:
+    """`with` context running on a side stream of a CUDA device, or inline on a CPU 'device'
+    (the CPU form only exists so the exchange logic can be exercised with gloo in tests)."""
+
+    def __init__(self, device, priority=0):
+        self.cuda = _is_cuda(device)
+        self.stream = torch.cuda.Stream(device, priority=priority) if self.cuda else None
+
+    def __enter__(self):
+        if self.cuda:
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.cuda:
+            self._ctx.__exit__(*a)
+        return False
+
+
+class DeviceDistributedPrefetcher(DeviceIterator):
+    def __init__(self, devices, it: Iterator[ProtoDistributedBatch], pipeline_on=True, ops=None, group=None):
+        super().__init__(devices)
+        self.it = it
+        self.pipeline_on = pipeline_on
+        self.group = group
+        cfg = self.it.session.config
+        self.partition_book = cfg.partition_book
+        self.cache = cfg.cache
+        self.use_cache = bool(cfg.use_cache)
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        assert self.world_size == int(self.partition_book.world_size), "partition book / process group mismatch"
+        assert self.rank == int(self.partition_book.rank)
+        self.other_ranks = [r for r in range(self.world_size) if r != self.rank]
+        self.ops = ops if ops is not None else _HipFeatureOps()
+        self.offsets = [int(v) for v in self.partition_book.partition_offsets.tolist()]
+        self.rank_offset = self.offsets[self.rank]
+        # all local rows, HBM resident (the session concatenated x_gpu and x_cpu)
+        self.features = getattr(self.it.session, "_x", None)
+        if self.features is None:
+            self.features = cfg.x_gpu
+        self.feature_dim = self.features.size(1)
+        self.features_dtype = self.features.dtype
+        if self.use_cache:
+            self.cache_feats = self.cache.device_features() if hasattr(self.cache, "device_features") \
+                else self.cache.cached_features
+        else:
+            self.cache_feats = None
+        self.side = _SideStream(self.device, priority=-1)
+        self.q_counts = deque()    # batches whose counts exchange is in flight
+        self.q_rows = deque()      # batches whose row exchange is in flight
+        self.next: Optional[list] = []
+        self.NUMBER_OF_SENT_BYTES = 0
+        self.ITERATION = 0
+        self._exhausted = False
+        depth = 2 if pipeline_on else 0
+        for _ in range(depth):
+            self._advance(produce_output=False)
+        self._advance(produce_output=True)
+
+    # ---- stages ----
+    def _stage_sample_and_counts(self):
+        if self._exhausted:
+            return
+        runtime_stats_cuda.start_region("sampling2")
+        proto = next(self.it, None)
+        runtime_stats_cuda.end_region("sampling2")
+        if proto is None:
+            self._exhausted = True
+            return
+        P = self.world_size
+        send_counts = [int(p.numel()) for p in proto.partition_nids]
+        dev = proto.perm_partition_to_mfg.device
+        sc = torch.tensor(send_counts, dtype=torch.int64).to(dev, non_blocking=True)
+        rc = torch.empty(P, dtype=torch.int64, device=dev)
+        h = dist.all_to_all_single(rc, sc, group=self.group, async_op=True)          # C1
+        self.q_counts.append((proto, send_counts, sc, rc, h))
+
+    def _stage_ids_serve_rows(self):
+        if not self.q_counts:
+            return
+        proto, send_counts, sc, rc, h = self.q_counts.popleft()
+        h.wait()
+        P, r = self.world_size, self.rank
+        recv_counts = [int(v) for v in rc.cpu().tolist()]      # host needs the split sizes
+        dev = proto.perm_partition_to_mfg.device
+        send_ids = torch.cat(proto.partition_nids) if len(proto.partition_nids) > 1 else proto.partition_nids[0]
+        recv_ids = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
+        h_ids = dist.all_to_all_single(recv_ids, send_ids, output_split_sizes=recv_counts,
+                                       input_split_sizes=send_counts, group=self.group, async_op=True)   # C2
+        h_ids.wait()
+        # serve: rows requested by the peers (own request is satisfied locally in the assembly)
+        own_lo = sum(recv_counts[:r])
+        own_hi = own_lo + recv_counts[r]
+        peer_ids = torch.cat([recv_ids[:own_lo], recv_ids[own_hi:]]) if P > 1 else recv_ids[:0]
+        send_rows = self.ops.gather_rows(self.features, peer_ids - self.rank_offset)
+        in_splits = [c if m != r else 0 for m, c in enumerate(recv_counts)]
+        out_splits = [c if m != r else 0 for m, c in enumerate(send_counts)]
+        recv_rows = torch.empty((sum(out_splits), self.feature_dim), dtype=self.features_dtype, device=dev)
+        h_rows = dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=out_splits,
+                                        input_split_sizes=in_splits, group=self.group, async_op=True)   # C3
+        self.NUMBER_OF_SENT_BYTES += sum(in_splits) * self.feature_dim * self.features.element_size() \
+            + sum(out_splits) * 8 + 8 * P
+        for t in (send_ids, recv_ids, send_rows, recv_rows, sc, rc):
+            if t.is_cuda and self.side.cuda:
+                t.record_stream(self.side.stream)
+        self.q_rows.append((proto, send_counts, recv_rows, send_rows, h_rows))
+
+    def _stage_assemble(self):
+        if not self.q_rows:
+            self.next = None
+            return
+        proto, send_counts, recv_rows, _send_rows, h_rows = self.q_rows.popleft()
+        h_rows.wait()
+        P, r = self.world_size, self.rank
+        seg = [0]
+        for m in range(P):
+            seg.append(seg[-1] + send_counts[m])
+        seg.append(seg[-1] + int(proto.cached_nids.numel()))
+        n_id = proto.n_id
+        if n_id is None:      # reference-style producer: rebuild the MFG order from the concat + perm
+            ids = torch.cat(list(proto.partition_nids) +
+                            ([self.cache.cached_vertices.to(proto.cached_nids.device)[proto.cached_nids]]
+                             if self.use_cache else []))
+            n_id = ids[proto.perm_partition_to_mfg]
+        x = self.ops.assemble(n_id, proto.perm_partition_to_mfg, seg, P, r, self.rank_offset, self.features,
+                              recv_rows, self.cache_feats, proto.cached_nids)
+        y = proto.sliced_cpu_labels
+        if y is not None and _is_cuda(self.device) and not y.is_cuda:
+            y = y.to(self.device, non_blocking=True)
+        self.next = [PreparedBatch(x, y, proto.adjs, proto.idx_range)]
+
+    def _advance(self, produce_output: bool):
+        with self.side:
+            if produce_output:
+                runtime_stats_cuda.start_region("stage_combine_features")
+                self._stage_assemble()
+                runtime_stats_cuda.end_region("stage_combine_features")
+            self._stage_ids_serve_rows()
+            self._stage_sample_and_counts()
+            if not self.pipeline_on and produce_output and self.next is None and (self.q_counts or self.q_rows):
+                # unpipelined mode: run the freshly sampled batch through all stages now
+                self._stage_ids_serve_rows()
+                self._stage_assemble()
+
+    def __next__(self):
+        ret = self.next
+        self.next = []
+        self.ITERATION += 1
+        runtime_stats_cuda.start_region("data_transfer", runtime_stats_cuda.get_last_event())
+        if self.side.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side.stream)
+        runtime_stats_cuda.end_region("data_transfer")
+        runtime_stats_cuda.start_region("sampling", runtime_stats_cuda.get_last_event())
+        if not ret:
+            if self.side.cuda:
+                torch.cuda.synchronize()
+            raise StopIteration
+        if self.side.cuda:
+            for b in ret:
+                b.record_stream(torch.cuda.current_stream(self.device))
+        self._advance(produce_output=True)
+        return ret
+
+    def print_stats(self):
+        return
+
+
+class DevicePrefetcher(DeviceIterator):
+    """Single-GPU double buffering (transferers.py:890-970): the next batch is sampled, sliced and
+    exported on a side stream while the model consumes the current one."""
+
+    def __init__(self, devices, it: Iterator[PreparedBatch], pipeline_on=True):
+        super().__init__(devices)
+        self.it = it
+        self.streams = [torch.cuda.Stream(device) for device in devices]
+        self.next = []
+        self.sampling_times = []
+        self.preload(False)
+
+    def preload(self, timing=True):
+        self.next = []
+        for device, stream in zip(self.devices, self.streams):
+            t0 = time.perf_counter_ns()
+            with torch.cuda.stream(stream):
+                batch = next(self.it, None)
+                if batch is None:
+                    break
+                self.next.append(batch.to(device, non_blocking=True))
+            self.sampling_times.append(time.perf_counter_ns() - t0)
+
+    def __next__(self):
+        runtime_stats_cuda.start_region("data_transfer", runtime_stats_cuda.get_last_event())
+        cur_streams = [torch.cuda.current_stream(device) for device in self.devices]
+        for cur_stream, stream in zip(cur_streams, self.streams):
+            cur_stream.wait_stream(stream)
+        runtime_stats_cuda.end_region("data_transfer")
+        runtime_stats_cuda.start_region("sampling", runtime_stats_cuda.get_last_event())
+        ret = self.next
+        if not ret:
+            torch.cuda.synchronize()
+            raise StopIteration
+        for cur_stream, batch in zip(cur_streams, ret):
+            batch.record_stream(cur_stream)
+        self.preload()
+        return ret
+
+
+class DeviceTransferer(DeviceIterator):
+    def __init__(self, devices, it: Iterator[PreparedBatch], pipeline_on=True):
+        super().__init__(devices)
+        self.it = it
+
+    def __next__(self):
+        ret = [batch.to(device, non_blocking=True) for device, batch in zip(self.devices, self.it)]
+        if len(ret) == 0:
+            raise StopIteration
+        return ret
+
+
+class DeviceSlicerTransferer(DeviceIterator):
+    def __init__(self, devices, x: torch.Tensor, y: torch.Tensor, it: Iterator[ProtoBatch]):
+        super().__init__(devices)
+        self.x = x
+        self.y = y
+        self.it = it
+
+    def __next__(self):
+        ret = [PreparedBatch.from_proto_batch(self.x, self.y, pb).to(device, non_blocking=True)
+               for device, pb in zip(self.devices, self.it)]
+        if len(ret) == 0:
+            raise StopIteration
+        return ret
