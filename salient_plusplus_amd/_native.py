@@ -99,6 +99,10 @@ def load():
             raise SppError(
                 f"{LIB_PATH} is missing: build it with `python -m salient_plusplus_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the
+        # system one).  It must be resident BEFORE this library is loaded so both resolve to the same
+        # runtime; loading /opt/rocm's copy first leaves torch without a usable device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

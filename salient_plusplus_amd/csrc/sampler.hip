@@ -31,6 +31,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include "mt19937.cuh"
+
 #include <algorithm>
 #include <vector>
 
@@ -38,7 +40,6 @@ namespace spp {
 
 spp_status gather_rows_i32(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n, void* dst,
                            hipStream_t st);
-__device__ void mt19937_wave_fill(uint32_t* x, uint32_t seed, int64_t skip, int64_t n, uint32_t* out);
 
 constexpr int kNT = 256;         // workgroup size of the per-target / per-edge kernels
 constexpr int kFastMaxFanout = 32;
@@ -68,7 +69,7 @@ struct SlotPtrs {
   unsigned long long* table;
   uint32_t tab_mask;
   uint32_t* rng;       // draws rng_skip .. of the batch stream
-  uint32_t* mt_ring;   // saved 1024-word LDS ring of the generator
+  uint32_t* mt_ring;   // saved LDS ring (kMtRing words) of the generator
   int32_t* bsum0;
   int32_t* bsum1;
   SlotState* st;
@@ -189,71 +190,32 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(SlotPtrs s, int32_t h, int
 // ----------------------------------------------------------------------------------------------
 // RNG: continue the batch's mt19937 stream (one wavefront) up to the draws hop h needs
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mt_temper_(uint32_t y) {
-  y ^= (y >> 11);
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= (y >> 18);
-  return y;
-}
-
 __global__ __launch_bounds__(64) void k_mt_advance(SlotPtrs s, int32_t h, int32_t f, uint32_t seed, int64_t skip,
                                                     int64_t dcap) {
-  __shared__ uint32_t x[1024];
+  __shared__ uint32_t x[kMtRing];
   const int lane = threadIdx.x;
   SlotState* st = s.st;
   int64_t pos = st->gen_pos;
-  // absolute number of outputs that must exist after this call
+  // number of draws (relative to skip) that must exist after this call
   const int64_t need_rel = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
   if (need_rel > dcap) {
     if (lane == 0) atomicOr(&st->error, kErrDrawCap);
     return;
   }
   const int64_t need = skip + need_rel;
+  const int64_t cap = dcap + kMtSlack;  // the rng buffer holds dcap + kMtSlack words
   if (pos < 0) {
-    if (lane == 0) {
-      uint32_t p = seed;  // std::mt19937::seed(value)
-      x[0] = p;
-      for (int i = 1; i < 624; ++i) {
-        p = 1812433253u * (p ^ (p >> 30)) + (uint32_t)i;
-        x[i] = p;
-      }
-    }
-    pos = 0;
+    mt_wave_seed(x, seed, skip, cap, s.rng);
+    pos = 624;
   } else {
     if (pos >= need) return;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[lane + 64 * k] = s.mt_ring[lane + 64 * k];
+    for (int k = 0; k < kMtRing / 64; ++k) x[lane + 64 * k] = s.mt_ring[lane + 64 * k];
+    mt_wave_sync();
   }
-  __syncthreads();
-  // pos is always a multiple of 227: output i is temper(x[624 + i]), 227 outputs per step
-  for (; pos < need; pos += 227) {
-    uint32_t v[4];
+  pos = mt_wave_advance(x, pos, need, skip, cap, s.rng);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int j = lane + 64 * m;
-      if (j < 227) {
-        const uint32_t nn = (uint32_t)((624 + pos + j) & 1023);
-        const uint32_t a = x[(nn - 624u) & 1023u];
-        const uint32_t b = x[(nn - 623u) & 1023u];
-        const uint32_t c = x[(nn - 227u) & 1023u];
-        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-        v[m] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int j = lane + 64 * m;
-      if (j < 227) {
-        x[(uint32_t)((624 + pos + j) & 1023)] = v[m];
-        const int64_t i = pos + j;
-        if (i >= skip && i - skip < dcap) s.rng[i - skip] = mt_temper_(v[m]);
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) s.mt_ring[lane + 64 * k] = x[lane + 64 * k];
+  for (int k = 0; k < kMtRing / 64; ++k) s.mt_ring[lane + 64 * k] = x[lane + 64 * k];
   if (lane == 0) st->gen_pos = pos;
 }
 
@@ -560,8 +522,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     A(p.deg, int32_t, tmax);
     A(p.rowstart, int64_t, tmax);
     A(p.table, unsigned long long, tab);
-    A(p.rng, uint32_t, s->dcap + 256);
-    A(p.mt_ring, uint32_t, 1024);
+    A(p.rng, uint32_t, s->dcap + kMtSlack);
+    A(p.mt_ring, uint32_t, kMtRing);
     A(p.bsum0, int32_t, nblk_max);
     A(p.bsum1, int32_t, nblk_max);
     A(p.st, SlotState, 1);

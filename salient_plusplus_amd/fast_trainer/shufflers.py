@@ -19,9 +19,10 @@ class Shuffler:
 
     def get_idx(self):
         self.generator.manual_seed(self.initial_seed + self.epoch)
-        perm = torch.randperm(self.initial_idx.numel(), generator=self.generator,
-                              device=self.initial_idx.device)
-        return self.initial_idx[perm]
+        # the permutation is always drawn by the CPU generator (what the reference does for its
+        # host-resident ids), so a given (seed, epoch) orders the ids identically wherever they live
+        perm = torch.randperm(self.initial_idx.numel(), generator=self.generator)
+        return self.initial_idx[perm.to(self.initial_idx.device)]
 
 
 class DistributedShuffler(Shuffler):
