@@ -13,7 +13,7 @@
 // GPU formulation, per hop (T = nodes collected so far = targets, all counts stay on the device):
 //   k_hop_count   lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
 //   k_hop_scan    1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
-//   k_mt_advance  1 wavefront : extend the batch's mt19937 stream to exactly the draws hop h needs
+//   k_mt_advance  1 workgroup : extend the batch's mt19937 stream to exactly the draws hop h needs
 //   k_hop_pick    lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
 //                               col reads; node-table insert with atomicMin(T + edge position)
 //   k_hop_flag    lane/edge   : table value -> "is first occurrence" flag, workgroup flag sums
@@ -190,33 +190,35 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(SlotPtrs s, int32_t h, int
 // ----------------------------------------------------------------------------------------------
 // RNG: continue the batch's mt19937 stream (one wavefront) up to the draws hop h needs
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_mt_advance(SlotPtrs s, int32_t h, int32_t f, uint32_t seed, int64_t skip,
-                                                    int64_t dcap) {
-  __shared__ uint32_t x[kMtRing];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(kMtThreads) void k_mt_advance(SlotPtrs s, int32_t h, int32_t f, uint32_t seed,
+                                                            int64_t skip, int64_t dcap) {
+  __shared__ uint32_t x[2 * kMtRing];
+  const int t = threadIdx.x;
   SlotState* st = s.st;
   int64_t pos = st->gen_pos;
   // number of draws (relative to skip) that must exist after this call
   const int64_t need_rel = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
   if (need_rel > dcap) {
-    if (lane == 0) atomicOr(&st->error, kErrDrawCap);
+    if (t == 0) atomicOr(&st->error, kErrDrawCap);
     return;
   }
   const int64_t need = skip + need_rel;
   const int64_t cap = dcap + kMtSlack;  // the rng buffer holds dcap + kMtSlack words
   if (pos < 0) {
-    mt_wave_seed(x, seed, skip, cap, s.rng);
+    mt_block_seed(x, seed, skip, cap, s.rng);
     pos = 624;
   } else {
     if (pos >= need) return;
-#pragma unroll
-    for (int k = 0; k < kMtRing / 64; ++k) x[lane + 64 * k] = s.mt_ring[lane + 64 * k];
-    mt_wave_sync();
+    for (int k = t; k < kMtRing; k += kMtThreads) {
+      const uint32_t v = s.mt_ring[k];
+      x[k] = v;
+      x[k + kMtRing] = v;
+    }
+    __syncthreads();
   }
-  pos = mt_wave_advance(x, pos, need, skip, cap, s.rng);
-#pragma unroll
-  for (int k = 0; k < kMtRing / 64; ++k) s.mt_ring[lane + 64 * k] = x[lane + 64 * k];
-  if (lane == 0) st->gen_pos = pos;
+  pos = mt_block_advance(x, pos, need, skip, cap, s.rng);
+  for (int k = t; k < kMtRing; k += kMtThreads) s.mt_ring[k] = x[k];
+  if (t == 0) st->gen_pos = pos;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -642,7 +644,7 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
     const int32_t ecap_dev = s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(sl.ecap_dyn[h], 0x7fffffff);
     hipLaunchKernelGGL(k_hop_scan, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, ecap_dev);
     if (f > 0)
-      hipLaunchKernelGGL(k_mt_advance, dim3(1), dim3(64), 0, st, sl.p, h, f, rng_seed, rng_skip, s->dcap);
+      hipLaunchKernelGGL(k_mt_advance, dim3(1), dim3(kMtThreads), 0, st, sl.p, h, f, rng_seed, rng_skip, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
       hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f, replace);

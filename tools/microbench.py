@@ -1,0 +1,84 @@
+"""Isolated timings of the C-ABI kernels on one MI355X (development aid, not part of the product)."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from salient_plusplus_amd import _native as nat  # noqa: E402
+from salient_plusplus_amd.synthetic import make_workload  # noqa: E402
+
+L = nat.load()
+nat.require_device()
+dev = torch.device("cuda", 0)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    what = sys.argv[1:] or ["mt", "gather", "sample"]
+    if "mt" in what:
+        for n in (15360, 163840, 1000000):
+            out = torch.empty(n, dtype=torch.int32, device=dev)
+            ms = timeit(lambda: L.spp_mt19937_fill(12345, 0, n, P(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            print(f"mt19937_fill n={n}: {ms*1e3:.1f} us  ({n/ms/1e6:.3f} G draws/s)", flush=True)
+    wl = None
+    if "gather" in what or "sample" in what:
+        wl = make_workload(os.environ.get("WL", "S-products"), device=dev)
+        torch.cuda.synchronize()
+    if "gather" in what:
+        N, F = wl.x.shape
+        for U in (100_000, 770_000):
+            idx = torch.randint(0, N, (U,), device=dev, dtype=torch.int64)
+            idx32 = idx.to(torch.int32)
+            out = torch.empty((U, F), dtype=wl.x.dtype, device=dev)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for name, ind, eb in (("i64", idx, 8), ("i32", idx32, 4)):
+                ms = timeit(lambda: L.spp_gather_rows(P(wl.x), N, F * 2, P(ind), eb, U, U, P(out), st))
+                print(f"gather U={U} F={F} idx={name}: {ms*1e3:.1f} us  alg {(U*(4*F+8))/ms/1e6:.1f} GB/s", flush=True)
+            ms = timeit(lambda: torch.index_select(wl.x, 0, idx))
+            print(f"torch.index_select U={U}: {ms*1e3:.1f} us  alg {(U*(4*F+8))/ms/1e6:.1f} GB/s", flush=True)
+    if "sample" in what:
+        cfg = nat.SamplerCfg()
+        cfg.rowptr_dev, cfg.col_dev = wl.rowptr.data_ptr(), wl.col.data_ptr()
+        cfg.num_nodes, cfg.nnz = wl.num_nodes, wl.col.numel()
+        cfg.num_hops = len(wl.fanouts)
+        for i, s in enumerate(wl.fanouts):
+            cfg.sizes[i] = s
+        cfg.max_batch, cfg.num_slots, cfg.device = wl.batch_size, 2, 0
+        h = C.c_void_p()
+        nat.check(L.spp_sampler_create(C.byref(cfg), C.byref(h)))
+        seeds = wl.train_idx[:wl.batch_size].contiguous()
+        cnt = nat.MfgCounts()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for it in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nat.check(L.spp_sampler_sample(h, 0, P(seeds), seeds.numel(), 17413, 0, st))
+            t1 = time.perf_counter()
+            nat.check(L.spp_sampler_wait(h, 0, C.byref(cnt)))
+            t2 = time.perf_counter()
+            print(f"sample: enqueue {1e6*(t1-t0):.0f} us, total latency {1e6*(t2-t0):.0f} us, U={cnt.num_nodes} "
+                  f"E={[cnt.E[k] for k in range(cnt.num_hops)]} draws={cnt.draws}", flush=True)
+        L.spp_sampler_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
