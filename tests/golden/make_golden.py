@@ -268,9 +268,12 @@ def part_dist(ref, out_dir):
     caches = {}
     for ci, (P, offs, rank, G, use_cache) in enumerate(cfgs):
         own_lo, own_hi = int(offs[rank]), int(offs[rank + 1])
-        x_local = xh[own_lo:own_hi]
-        x_gpu = T(x_local[:G].copy())
-        x_cpu = T(x_local[G:].copy())
+        # split the way the driver does (base.py:107-116): torch slices keep row-major strides
+        # even when one side is empty (a numpy copy of an empty slice trips the reference's
+        # "input must be 2D row-major tensor" check, fast_sampler.cpp:243-245)
+        x_local = T(xh[own_lo:own_hi].copy())
+        x_gpu = x_local[:G]
+        x_cpu = x_local[G:]
         if use_cache:
             key = (P, rank)
             if key not in caches:     # each Cache leaks ~1 GB of lookup tables: build few
@@ -315,9 +318,10 @@ def part_dist(ref, out_dir):
             d[f"{tag}_b{bi}_perm"] = b.perm_partition_to_mfg.numpy().copy()
             d[f"{tag}_b{bi}_cpu_feats"] = b.sliced_cpu_features.numpy().copy()
             d[f"{tag}_b{bi}_labels"] = b.sliced_cpu_labels.numpy().copy()
-            for hi, (rp, cl, e_id, sz) in enumerate(b.adjs):
-                d[f"{tag}_b{bi}_h{hi}_rowptr"] = rp.numpy().copy()
-                d[f"{tag}_b{bi}_h{hi}_col"] = cl.numpy().copy()
+            # the MFG itself (b.adjs) is the same sampler output already pinned by mfg_a_*.npz and
+            # is not stored again; the concat + perm identity below ties the two together
+            ids = torch.cat(list(b.partition_nids) + ([T(cv)[b.cached_nids]] if use_cache else []))
+            d[f"{tag}_b{bi}_n_id"] = ids[b.perm_partition_to_mfg].numpy().copy()
             bi += 1
         d[f"{tag}_num_batches"] = np.array(bi)
         del s

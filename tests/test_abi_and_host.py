@@ -1,0 +1,162 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/spp.h declares; host-side
+logic of the facade (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "spp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(spp_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd import build
+    build.build()
+    L = nat.load()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for name in syms:
+        assert hasattr(L, name), f"{name} declared in include/spp.h but not exported"
+        assert name in nat.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(nat.SIGNATURES) == set(syms)
+    assert L.spp_abi_version() == 1
+    assert L.spp_batch_seed(64) == 64 * 17 + 5
+
+
+def test_struct_layouts_match_header():
+    """sizeof of the by-pointer structs, cross-checked by compiling the header with gcc."""
+    import subprocess
+    import tempfile
+    from salient_plusplus_amd import _native as nat
+    prog = r'''
+#include <stdio.h>
+#include "spp.h"
+int main(void) { printf("%zu %zu %zu %zu %zu\n", sizeof(spp_sampler_cfg), sizeof(spp_mfg_counts),
+                        sizeof(spp_mfg_out), sizeof(spp_session_cfg), sizeof(spp_batch_desc)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(nat.SamplerCfg), ctypes.sizeof(nat.MfgCounts), ctypes.sizeof(nat.MfgOut),
+                     ctypes.sizeof(nat.SessionCfg), ctypes.sizeof(nat.BatchDesc)]
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd import fast_sampler as fs
+    with pytest.raises(nat.SppError):
+        fs.serial_index(torch.zeros(4, 2), torch.zeros(1, dtype=torch.int64))
+    cfg = fs.Config()
+    cfg.rowptr, cfg.col, cfg.idx = torch.zeros(2, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), \
+        torch.zeros(1, dtype=torch.int64)
+    cfg.batch_size, cfg.sizes = 1, [1]
+    with pytest.raises(nat.SppError):
+        fs.Session(1, 1, cfg)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under salient_plusplus_amd/ may import, link or
+    execute it (no CPU fallback on the product path)."""
+    pkg = os.path.join(ROOT, "salient_plusplus_amd")
+    bad = re.compile(r"(^|\n)\s*(from|import)\s+oracle\b|liborc|spp_oracle|orc_[a-z_]+\(")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(text), f"{os.path.join(dirpath, f)} references the oracle"
+
+
+def test_config_facade_num_batches_and_field_set(golden_dir):
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSamplerConfig
+    from oracle import oracle as orc
+    base = dict(x_cpu=torch.zeros(1, 1), x_gpu=torch.empty(0), y=torch.zeros(1), rowptr=torch.zeros(2),
+                col=torch.zeros(0), batch_size=64, sizes=[15, 10, 5], pin_memory=False, distributed=False,
+                partition_book=None, cache=fs.Cache(), count_remote_frequency=False, use_cache=False)
+    for n in (200, 128, 10, 64):
+        for skip in (False, True):
+            cfg = FastSamplerConfig(idx=torch.zeros(n, dtype=torch.int64), skip_nonfull_batch=skip,
+                                    force_exact_num_batches=False, exact_num_batches=0, **base)
+            assert cfg.get_num_batches() == orc.batch_ranges(n, 64, skip).shape[0]
+    cfg = FastSamplerConfig(idx=torch.zeros(300, dtype=torch.int64), skip_nonfull_batch=False,
+                            force_exact_num_batches=True, exact_num_batches=4, **base)
+    assert cfg.get_num_batches() == 4 == orc.batch_ranges(300, 64, False, True, 4).shape[0]
+    native = cfg.to_fast_sampler()
+    # the rw fields of the reference's Config (fast_sampler.cpp:1290-1309)
+    for f in ["x_cpu", "x_gpu", "y", "rowptr", "col", "idx", "batch_size", "sizes", "skip_nonfull_batch",
+              "pin_memory", "distributed", "partition_book", "cache", "force_exact_num_batches",
+              "exact_num_batches", "count_remote_frequency", "use_cache"]:
+        assert hasattr(native, f)
+    assert isinstance(native.partition_book, fs.RangePartitionBook)   # skipped when not distributed
+
+
+def test_adj_mapping_and_batch_records():
+    from salient_plusplus_amd.fast_trainer.samplers import (Adj__from_fast_sampler, PreparedBatch,
+                                                             ProtoDistributedBatch)
+    rowptr = torch.tensor([0, 2, 3]); col = torch.tensor([0, 2, 1]); e_id = torch.empty(0, dtype=torch.int64)
+    adj = Adj__from_fast_sampler((rowptr, col, e_id, (2, 3)))
+    assert tuple(adj.size) == (3, 2)                       # sparse_sizes[::-1]
+    assert tuple(adj.adj_t.sparse_sizes()) == (2, 3)
+    rp, cl, val = adj.adj_t.csr()
+    assert torch.equal(rp, rowptr) and torch.equal(cl, col) and val is None
+    pb = PreparedBatch.from_fast_sampler((torch.zeros(3, 4), torch.arange(2).unsqueeze(-1), [(rowptr, col, e_id, (2, 3))], (5, 7)))
+    assert pb.batch_size == 2 and pb.num_total_nodes == 3 and pb.y.shape == (2,)
+    assert pb.idx_range == slice(5, 7)
+    pb.record_stream(None)                                 # CPU tensors: no-op
+    pb2 = pb.to("cpu")
+    assert torch.equal(pb2.x, pb.x)
+
+    class Raw:
+        partition_nids = [torch.tensor([1, 2]), torch.tensor([7])]
+        sliced_cpu_features = torch.empty(0, 4)
+        sliced_cpu_labels = torch.tensor([[1], [0]])
+        cached_nids = torch.empty(0, dtype=torch.int64)
+        perm_partition_to_mfg = torch.tensor([0, 2, 1])
+        adjs = [(rowptr, col, e_id, (2, 3))]
+        idx_range = (0, 2)
+    proto = ProtoDistributedBatch.from_fast_sampler(Raw)
+    assert proto.num_total_nodes == 3 and proto.num_cached_nodes == 0
+    assert proto.get_num_local_nodes(0) == 2 and proto.get_num_communicated_nodes(0) == 1
+    assert proto.idx_range == slice(0, 2)
+
+
+def test_shufflers_follow_reference_seeding():
+    from salient_plusplus_amd.fast_trainer.shufflers import DistributedShuffler, Shuffler
+    idx = torch.arange(100, 200)
+    s = Shuffler(idx)
+    s.set_epoch(3)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2147483647 + 3)                          # shufflers.py:25-29
+    want = idx[torch.randperm(100, generator=g)]
+    assert torch.equal(s.get_idx(), want)
+    d = DistributedShuffler(idx, 4)
+    d.set_epoch(3)
+    parts = [d.get_idx(r) for r in range(4)]
+    assert torch.equal(torch.cat(parts), want)
+    assert [p.numel() for p in parts] == [25, 25, 25, 25]
+
+
+def test_range_partition_book_host_side(golden_dir):
+    from salient_plusplus_amd import fast_sampler as fs
+    p = np.load(os.path.join(golden_dir, "partition_book.npz"))
+    pb = fs.RangePartitionBook(2, 4, torch.from_numpy(p["offsets"]))
+    nids = torch.from_numpy(p["nids"])
+    np.testing.assert_array_equal(pb.nid2partid(nids).numpy(), p["partid"])
+    np.testing.assert_array_equal(pb.nid2localnid(nids, 2).numpy(), p["localnid_p2"])
+    np.testing.assert_array_equal(pb.partid2nids(1).numpy(), p["partid2nids_1"])
+    assert pb.nid_is_local(torch.tensor([1499, 1500, 2099, 2100])).tolist() == [False, True, True, False]

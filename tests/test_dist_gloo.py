@@ -1,0 +1,178 @@
+"""CPU, world_size 2, gloo: the N>1 exchange path of DeviceDistributedPrefetcher (counts -> ids ->
+rows all_to_all_single, split bookkeeping, own-slot handling, pipelining, final assembly).
+
+The device kernels are replaced HERE, in test code, by oracle-backed stand-ins injected through the
+`ops` argument; the batches come from the oracle's restatement of the distributed worker branch.
+The product never selects these stand-ins by itself."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P = 2
+SIZES = [15, 10, 5]
+
+
+class OracleOps:
+    """Reference semantics of the two feature kernels, for CPU tensors."""
+
+    def gather_rows(self, x, idx):
+        from oracle import oracle as orc
+        return torch.from_numpy(orc.serial_index(x.numpy(), idx.numpy()))
+
+    def assemble(self, n_id, perm, seg_start, P_, rank, rank_offset, x_local, recv, cache_feats, cached_nids):
+        # transferers.py:472-486: x = cat(features_gather + [cached])[perm]
+        parts = []
+        recv_at = 0
+        own_ids = None
+        for m in range(P_):
+            n = seg_start[m + 1] - seg_start[m]
+            if m == rank:
+                parts.append(None)
+            else:
+                parts.append(recv[recv_at:recv_at + n])
+                recv_at += n
+        # the own segment: local rows of the nodes whose perm falls into it, in segment order
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        own_ids = n_id[inv[seg_start[rank]:seg_start[rank + 1]]]
+        parts[rank] = x_local[own_ids - rank_offset]
+        if seg_start[P_ + 1] > seg_start[P_]:
+            parts.append(cache_feats[cached_nids])
+        return torch.cat(parts, dim=0)[perm]
+
+
+class _StubCache:
+    def __init__(self, cached_vertices, cached_features):
+        self.cached_vertices = cached_vertices
+        self.cached_features = cached_features
+
+
+class _StubPB:
+    def __init__(self, rank, world_size, offsets):
+        self.rank, self.world_size, self.partition_offsets = rank, world_size, offsets
+
+
+class _StubConfig:
+    pass
+
+
+class _StubSession:
+    pass
+
+
+class OracleProtoIter:
+    """Stands in for FastSamplerIter in distributed mode: yields ProtoDistributedBatch records
+    computed by the oracle (fast_sampler.cpp:1017-1262 restated in oracle/spp_oracle.c)."""
+
+    def __init__(self, g, rank, offsets, use_cache, cv, n_batches):
+        from oracle import oracle as orc
+        from salient_plusplus_amd.fast_trainer.samplers import Adj__from_fast_sampler, ProtoDistributedBatch
+        self.orc, self.Adj, self.Proto = orc, Adj__from_fast_sampler, ProtoDistributedBatch
+        self.g, self.rank, self.offsets = g, rank, offsets
+        n = g["rowptr"].shape[0] - 1
+        self.ocache = orc.Cache(cv, n) if use_cache else None
+        # each rank trains on its own slice of the seeds
+        idx = g["idx"]
+        self.idx = idx[(len(idx) * rank) // P:(len(idx) * (rank + 1)) // P]
+        self.ranges = orc.batch_ranges(len(self.idx), 64, False, True, n_batches)
+        self.b = 0
+        lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+        x = torch.from_numpy(g["x"])
+        cfg = _StubConfig()
+        cfg.partition_book = _StubPB(rank, P, torch.from_numpy(offsets))
+        cfg.cache = _StubCache(torch.from_numpy(cv), x[torch.from_numpy(cv)]) if use_cache else _StubCache(
+            torch.empty(0, dtype=torch.int64), torch.empty((0, 0), dtype=torch.float16))
+        cfg.use_cache = use_cache
+        cfg.x_gpu = x[lo:hi].contiguous()
+        cfg.x_cpu = x[:0]
+        self.session = _StubSession()
+        self.session.config = cfg
+        self.expected = []
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.b >= len(self.ranges):
+            raise StopIteration
+        start, stop = (int(v) for v in self.ranges[self.b])
+        self.b += 1
+        g = self.g
+        m = self.orc.sample_batch(g["rowptr"], g["col"], self.idx, start, stop, SIZES)
+        p = self.orc.partition_batch(m.n_id, self.offsets, self.rank, self.ocache, 0)
+        T = torch.from_numpy
+        e_id = torch.empty(0, dtype=torch.int64)
+        adjs = [self.Adj((T(h.rowptr), T(h.col), e_id, h.size)) for h in m.hops]
+        y = T(g["y"][m.n_id[:stop - start]]).unsqueeze(-1)
+        self.expected.append(m.n_id)
+        return self.Proto(partition_nids=[T(a) for a in p.partition_nids],
+                          sliced_cpu_features=torch.empty((0, g["x"].shape[1]), dtype=torch.float16),
+                          sliced_cpu_labels=y, cached_nids=T(p.cached_nids),
+                          perm_partition_to_mfg=T(p.perm_partition_to_mfg), adjs=adjs,
+                          idx_range=slice(start, stop), n_id=T(m.n_id))
+
+
+def _worker(rank, port, use_cache, pipeline_on, n_batches, fail_q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=P)
+        from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher
+        g = np.load(os.path.join(ROOT, "tests", "golden", "graph_a.npz"))
+        g = {k: g[k] for k in g.files}
+        n = g["rowptr"].shape[0] - 1
+        offsets = np.array([0, 1400, n], dtype=np.int64)
+        lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+        rng = np.random.default_rng(100 + rank)
+        remote = np.setdiff1d(np.arange(n), np.arange(lo, hi))
+        cv = np.sort(rng.choice(remote, size=250, replace=False)).astype(np.int64)
+        it = OracleProtoIter(g, rank, offsets, use_cache, cv, n_batches)
+        devit = DeviceDistributedPrefetcher([torch.device("cpu")], it, pipeline_on, ops=OracleOps())
+        got = 0
+        for (batch,) in devit:
+            n_id = it.expected[got]
+            want = g["x"][n_id]
+            assert batch.x.shape == want.shape
+            np.testing.assert_array_equal(batch.x.numpy().view(np.uint16), want.view(np.uint16))
+            start, stop = batch.idx_range.start, batch.idx_range.stop
+            np.testing.assert_array_equal(batch.y.numpy().reshape(-1), g["y"][n_id[:stop - start]])
+            assert len(batch.adjs) == len(SIZES)
+            got += 1
+        assert got == n_batches
+        assert devit.NUMBER_OF_SENT_BYTES > 0
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        fail_q.put(f"rank {rank}: {e}\n{traceback.format_exc()}")
+        raise
+
+
+@pytest.mark.parametrize("use_cache,pipeline_on,n_batches", [(False, True, 4), (True, True, 3), (True, False, 2),
+                                                             (False, True, 1)])
+def test_distributed_prefetcher_two_ranks_gloo(use_cache, pipeline_on, n_batches):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29650 + (hash((use_cache, pipeline_on, n_batches)) % 200)
+    procs = [ctx.Process(target=_worker, args=(r, port, use_cache, pipeline_on, n_batches, q)) for r in range(P)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    msgs = []
+    while not q.empty():
+        msgs.append(q.get())
+    assert not alive, "rank(s) hung"
+    assert all(p.exitcode == 0 for p in procs), "\n".join(msgs)

@@ -237,3 +237,35 @@ def test_distributed_prefetcher_world_size_1_rccl(fs, graph_a):
             assert nb == 3
     finally:
         dist.destroy_process_group()
+
+
+def test_distributed_proto_batch_vs_reference_golden(fs, graph_a, golden_dir):
+    """Against the compiled reference's own distributed batches (tests/golden/distributed.npz,
+    generated on the GPU box): ownership buckets, cache indices, permutation, labels, node order."""
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    g = np.load(os.path.join(golden_dir, "distributed.npz"))
+    x = graph_a["x"]
+    n_checked = 0
+    for ci in range(int(g["num_cfgs"])):
+        tag = f"c{ci}"
+        P, rank, G, use_cache = (int(v) for v in g[f"{tag}_meta"])
+        if G != 100:            # G only changes which local rows the reference slices on the host
+            continue
+        offs = g[f"{tag}_offsets"]
+        lo, hi = int(offs[rank]), int(offs[rank + 1])
+        cv = g[f"{tag}_cached_vertices"]
+        cache = fs.Cache(rank, P, T(cv), T(x[cv].copy())) if use_cache else fs.Cache()
+        cfg = make_cfg(fs, graph_a, [15, 10, 5], 64, x[lo:hi][G:].copy(), graph_a["y"], graph_a["idx"],
+                       x_gpu=T(x[lo:hi][:G].copy()).cuda(), distributed=True,
+                       partition_book=fs.RangePartitionBook(rank, P, T(offs)), cache=cache,
+                       force_exact_num_batches=True, exact_num_batches=3, use_cache=bool(use_cache))
+        for b, proto in enumerate(iter(FastSampler(2, 4, cfg))):
+            assert (proto.idx_range.start, proto.idx_range.stop) == tuple(int(v) for v in g[f"{tag}_b{b}_range"])
+            for m in range(P):
+                np.testing.assert_array_equal(proto.partition_nids[m].cpu().numpy(), g[f"{tag}_b{b}_part{m}"])
+            np.testing.assert_array_equal(proto.cached_nids.cpu().numpy(), g[f"{tag}_b{b}_cached_nids"])
+            np.testing.assert_array_equal(proto.perm_partition_to_mfg.cpu().numpy(), g[f"{tag}_b{b}_perm"])
+            np.testing.assert_array_equal(proto.sliced_cpu_labels.cpu().numpy(), g[f"{tag}_b{b}_labels"])
+            np.testing.assert_array_equal(proto.n_id.cpu().numpy(), g[f"{tag}_b{b}_n_id"])
+            n_checked += 1
+    assert n_checked == 8 * 3
