@@ -34,11 +34,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-products"))
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "8")))
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "24")))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache-frac", type=float, default=0.10)
     return ap.parse_args()
+
+
+def host_cpu_share() -> int:
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def count_edges(batch) -> int:
@@ -268,7 +280,7 @@ def main():
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
-            threads = len(os.sched_getaffinity(0))
+            threads = host_cpu_share()
             host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
             out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -214,8 +214,10 @@ typedef struct spp_session_cfg {
   int32_t skip_nonfull_batch;
   int32_t force_exact_num_batches;
   int64_t exact_num_batches;
-  int32_t max_items_in_queue;      /* batches in flight (slots)                */
-  int32_t num_streams;             /* HIP streams the slots are spread over (0 = default 4) */
+  int32_t max_items_in_queue;      /* upper bound on batches in flight (slots) */
+  int32_t group_size;              /* batches sampled per launch sequence (0 = auto: max_items/3, <= 8);
+                                      max_items_in_queue / group_size slot-sets are in flight, one HIP
+                                      stream each */
   int32_t device;
   /* Optional: borrow an existing sampler (same graph, fanouts; max_batch and num_slots at least
    * what this epoch needs) instead of allocating workspace per epoch -- the counterpart of the

@@ -39,7 +39,7 @@ class SessionCfg(C.Structure):
                 ("idx_dev", p), ("n_idx", i64), ("batch_size", i64), ("num_hops", i32),
                 ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
                 ("force_exact_num_batches", i32), ("exact_num_batches", i64),
-                ("max_items_in_queue", i32), ("num_streams", i32), ("device", i32), ("sampler", p)]
+                ("max_items_in_queue", i32), ("group_size", i32), ("device", i32), ("sampler", p)]
 
 
 class BatchDesc(C.Structure):

@@ -10,10 +10,11 @@
 //     emission order) through a running map shared by all hops (sample_cpu.hpp:50-60);
 //   * each output row sorted by local id (sample_cpu.hpp:126).
 //
-// GPU formulation, per hop (T = nodes collected so far = targets, all counts stay on the device):
+// GPU formulation.  A launch processes a GROUP of up to 16 independent batches (blockIdx.y selects
+// the batch slot) so that even the small first hops put >> 256 workgroups on the chip.  Per hop
+// (T = nodes collected so far = targets; all counts stay on the device):
 //   k_hop_count   lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
 //   k_hop_scan    1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
-//   k_mt_advance  1 workgroup : extend the batch's mt19937 stream to exactly the draws hop h needs
 //   k_hop_pick    lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
 //                               col reads; node-table insert with atomicMin(T + edge position)
 //   k_hop_flag    lane/edge   : table value -> "is first occurrence" flag, workgroup flag sums
@@ -21,20 +22,25 @@
 //   k_hop_assign  lane/edge   : rank of every first occurrence -> new local id, n_ids append,
 //                               table value finalised
 //   k_hop_rows    lane/target : local ids of the row, LDS rank-sort, out_col
+// The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
+// one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
+// the ~0.5 ms serial recurrence never sits on the sampling critical path.
 // The node table is an open-addressing hash table in HBM (64-bit slots: key<<32 | value) sized
 // 2x the worst-case node count, so it stays Infinity-Cache resident; value < T means "final local
 // id", value >= T means "T + position of the earliest edge that reaches this node in this hop".
 //
 // Hops with fanout < 0 (all neighbours) or fanout > 32 take a generic path (edge-parallel expand,
-// hipcub segmented sort, one host sync per hop to size the launch).
+// hipcub segmented sort, one host sync per hop to size the launch); such samplers run one batch
+// per launch.
 #include "spp_internal.h"
 
 #include <hipcub/hipcub.hpp>
 
-#include "mt19937.cuh"
-
 #include <algorithm>
 #include <vector>
+
+#include "mt19937.cuh"
+#include "sampler_internal.h"
 
 namespace spp {
 
@@ -53,7 +59,6 @@ struct SlotState {
   int32_t E[SPP_MAX_HOPS];         // sampled edges of hop h
   int32_t nsmp[SPP_MAX_HOPS];      // targets with deg > fanout in hop h
   int64_t dbase[SPP_MAX_HOPS + 1]; // RNG draws consumed before hop h (relative to rng_skip)
-  int64_t gen_pos;                 // absolute number of mt19937 outputs generated so far
   int32_t error;
   int32_t pad;
 };
@@ -68,8 +73,7 @@ struct SlotPtrs {
   int32_t* erank;      // exclusive rank among first occurrences (also Floyd scratch, generic path)
   unsigned long long* table;
   uint32_t tab_mask;
-  uint32_t* rng;       // draws rng_skip .. of the batch stream
-  uint32_t* mt_ring;   // saved LDS ring (kMtRing words) of the generator
+  uint32_t* rng[2];    // draws rng_skip .. of the batch stream (ping-pong: generated one group ahead)
   int32_t* bsum0;
   int32_t* bsum1;
   SlotState* st;
@@ -77,9 +81,25 @@ struct SlotPtrs {
   int32_t* out_col[SPP_MAX_HOPS];
 };
 
+// per-launch description of a group of batches (passed by value)
+struct GroupArgs {
+  int32_t first_slot;
+  int32_t n;
+  int32_t rng_buf;
+  const int64_t* seeds[kMaxGroup];
+  int32_t n_seeds[kMaxGroup];
+  uint32_t rng_seed[kMaxGroup];
+  int64_t rng_skip[kMaxGroup];
+};
+
 // ----------------------------------------------------------------------------------------------
 // node table
 // ----------------------------------------------------------------------------------------------
+// Insert-or-update with min (kMax = false) / max (kMax = true) on the value.  The plain probe load
+// may be stale, but a slot only ever moves EMPTY -> key and its value only moves in the update
+// direction, so a stale value can only cause a redundant atomic, never a missed one.  Nodes that
+// are already final (value < T) and repeated neighbours therefore cost no atomic at all -- global
+// atomics to scattered lines run at a fraction of the HBM rate (MI355X_MICROARCH, float atomics).
 template <bool kMax>
 __device__ __forceinline__ uint32_t table_upsert(unsigned long long* table, uint32_t mask, uint32_t key,
                                                  uint32_t val) {
@@ -92,23 +112,41 @@ __device__ __forceinline__ uint32_t table_upsert(unsigned long long* table, uint
       if (cur == kEmptySlot) return h;
     }
     if ((uint32_t)(cur >> 32) == key) {
-      if (kMax) atomicMax(&table[h], entry);
-      else atomicMin(&table[h], entry);
+      const uint32_t have = (uint32_t)cur;
+      if (kMax) {
+        if (have < val) atomicMax(&table[h], entry);
+      } else {
+        if (have > val) atomicMin(&table[h], entry);
+      }
       return h;
     }
     h = (h + 1) & mask;
   }
 }
 
+// the batch's mt19937 stream: draws [skip, skip + dcap) of mt19937(seed) -> rng[buf]
+__global__ __launch_bounds__(kMtThreads) void k_rng_fill(const SlotPtrs* __restrict__ slots, GroupArgs ga,
+                                                          int64_t dcap) {
+  __shared__ uint32_t x[2 * kMtRing];
+  const SlotPtrs& s = slots[ga.first_slot + blockIdx.y];
+  const uint32_t seed = ga.rng_seed[blockIdx.y];
+  const int64_t skip = ga.rng_skip[blockIdx.y];
+  uint32_t* out = s.rng[ga.rng_buf];
+  const int64_t cap = dcap + kMtSlack;
+  mt_block_seed(x, seed, skip, cap, out);
+  mt_block_advance(x, 624, skip + dcap, skip, cap, out);
+}
+
 // get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
-// seed keeps its LAST position -> atomicMax.
-__global__ __launch_bounds__(kNT) void k_seed_init(SlotPtrs s, const int64_t* __restrict__ seeds, int32_t n_seeds,
-                                                    int64_t rng_skip) {
+// seed keeps its LAST position -> max.
+__global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga) {
+  const SlotPtrs& s = slots[ga.first_slot + blockIdx.y];
+  const int64_t* __restrict__ seeds = ga.seeds[blockIdx.y];
+  const int32_t n_seeds = ga.n_seeds[blockIdx.y];
   const int i = blockIdx.x * kNT + threadIdx.x;
   if (i == 0) {
     s.st->cnt[0] = n_seeds;
     s.st->dbase[0] = 0;
-    s.st->gen_pos = -1;  // generator not seeded yet
     s.st->error = 0;
   }
   if (i < n_seeds) {
@@ -133,9 +171,11 @@ __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t re
   cnt = smp ? f : (deg > 0 ? deg : 0);
 }
 
-__global__ __launch_bounds__(kNT) void k_hop_count(SlotPtrs s, const int64_t* __restrict__ rowptr, int32_t h,
-                                                    int32_t f, int32_t replace) {
+__global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                    const int64_t* __restrict__ rowptr, int32_t h, int32_t f,
+                                                    int32_t replace) {
   __shared__ int32_t lds[2][kNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
   const int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x;
   if ((int64_t)blockIdx.x * kNT >= T) return;
@@ -173,8 +213,10 @@ __device__ int32_t scan_block_sums(int32_t* a, int32_t n, int32_t* lds) {
   return carry;
 }
 
-__global__ __launch_bounds__(kScanNT) void k_hop_scan(SlotPtrs s, int32_t h, int32_t f, int32_t ecap) {
+__global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                       int32_t h, int32_t f, int32_t ecap, int64_t dcap) {
   __shared__ int32_t lds[kScanNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
   const int32_t nblk = (T + kNT - 1) / kNT;
   const int32_t E = scan_block_sums(s.bsum0, nblk, lds);
@@ -184,51 +226,20 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(SlotPtrs s, int32_t h, int
     s.st->nsmp[h] = S;
     s.out_rowptr[h][T] = E;
     if (E > ecap) atomicOr(&s.st->error, kErrEdgeCap);
+    if (s.st->dbase[h] + (int64_t)(f > 0 ? f : 0) * S > dcap) atomicOr(&s.st->error, kErrDrawCap);
   }
-}
-
-// ----------------------------------------------------------------------------------------------
-// RNG: continue the batch's mt19937 stream (one wavefront) up to the draws hop h needs
-// ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kMtThreads) void k_mt_advance(SlotPtrs s, int32_t h, int32_t f, uint32_t seed,
-                                                            int64_t skip, int64_t dcap) {
-  __shared__ uint32_t x[2 * kMtRing];
-  const int t = threadIdx.x;
-  SlotState* st = s.st;
-  int64_t pos = st->gen_pos;
-  // number of draws (relative to skip) that must exist after this call
-  const int64_t need_rel = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
-  if (need_rel > dcap) {
-    if (t == 0) atomicOr(&st->error, kErrDrawCap);
-    return;
-  }
-  const int64_t need = skip + need_rel;
-  const int64_t cap = dcap + kMtSlack;  // the rng buffer holds dcap + kMtSlack words
-  if (pos < 0) {
-    mt_block_seed(x, seed, skip, cap, s.rng);
-    pos = 624;
-  } else {
-    if (pos >= need) return;
-    for (int k = t; k < kMtRing; k += kMtThreads) {
-      const uint32_t v = s.mt_ring[k];
-      x[k] = v;
-      x[k + kMtRing] = v;
-    }
-    __syncthreads();
-  }
-  pos = mt_block_advance(x, pos, need, skip, cap, s.rng);
-  for (int k = t; k < kMtRing; k += kMtThreads) s.mt_ring[k] = x[k];
-  if (t == 0) st->gen_pos = pos;
 }
 
 // ----------------------------------------------------------------------------------------------
 // picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
 // ----------------------------------------------------------------------------------------------
 template <bool kGeneric>
-__global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
+__global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                   int32_t rng_buf, const int64_t* __restrict__ col, int32_t h,
                                                    int32_t f, int32_t replace) {
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
-  __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, column per lane
+  __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, then neighbour ids; column per lane
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
   if ((int64_t)blockIdx.x * kNT >= T) return;
   const int32_t i = blockIdx.x * kNT + threadIdx.x;
@@ -243,7 +254,8 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
   if (i >= T) return;
   s.out_rowptr[h][i] = p0;
   if (s.st->error) return;
-  const uint32_t* rng = smp ? (s.rng + s.st->dbase[h] + (int64_t)f * r0) : s.rng;
+  const uint32_t* rng = s.rng[rng_buf];
+  if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
   if (kGeneric) {
     // only the Floyd picks are produced here (into erank[p0..p0+f)); expansion is edge-parallel
     if (smp) {
@@ -280,9 +292,14 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
       chosen[k][tid] = found ? j : option;
     }
   }
+  // all neighbour reads of the row are issued back to back (independent HBM misses) ...
   for (int32_t k = 0; k < cnt; ++k) {
     const int32_t w = smp ? chosen[k][tid] : k;
-    const int32_t c = (int32_t)col[rs + w];
+    chosen[k][tid] = (int32_t)col[rs + w];
+  }
+  // ... before the (serialising) table updates
+  for (int32_t k = 0; k < cnt; ++k) {
+    const int32_t c = chosen[k][tid];
     const int32_t p = p0 + k;
     s.cval[p] = c;
     s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, T_u + (uint32_t)p);
@@ -290,8 +307,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(SlotPtrs s, const int64_t* __r
 }
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
-__global__ __launch_bounds__(kNT) void k_hop_expand_generic(SlotPtrs s, const int64_t* __restrict__ col, int32_t h,
-                                                             int32_t f, int32_t replace) {
+__global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                             const int64_t* __restrict__ col, int32_t h, int32_t f,
+                                                             int32_t replace) {
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
   const int32_t E = s.st->E[h];
   const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
@@ -316,8 +335,9 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(SlotPtrs s, const in
 // ----------------------------------------------------------------------------------------------
 // first-occurrence ranking
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNT) void k_hop_flag(SlotPtrs s, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h) {
   __shared__ int32_t lds[kNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t E = s.st->E[h];
   if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
   const uint32_t T = (uint32_t)s.st->cnt[h];
@@ -333,8 +353,10 @@ __global__ __launch_bounds__(kNT) void k_hop_flag(SlotPtrs s, int32_t h) {
   if (threadIdx.x == 0) s.bsum0[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(kScanNT) void k_hop_scan2(SlotPtrs s, int32_t h, int32_t f, int32_t ucap) {
+__global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                        int32_t h, int32_t f, int32_t ucap) {
   __shared__ int32_t lds[kScanNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   SlotState* st = s.st;
   if (st->error) {
     if (threadIdx.x == 0) {
@@ -354,8 +376,10 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan2(SlotPtrs s, int32_t h, in
   }
 }
 
-__global__ __launch_bounds__(kNT) void k_hop_assign(SlotPtrs s, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_assign(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                     int32_t h) {
   __shared__ int32_t lds[kNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t E = s.st->E[h];
   if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
   const uint32_t T = (uint32_t)s.st->cnt[h];
@@ -381,8 +405,9 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, in
 }
 
 // fast path: one lane per target row, rank sort of <= 32 local ids staged in LDS
-__global__ __launch_bounds__(kNT) void k_hop_rows(SlotPtrs s, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h) {
   __shared__ int32_t a[kFastMaxFanout][kNT];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
   const int32_t i = blockIdx.x * kNT + threadIdx.x;
   if (i >= T || s.st->error) return;
@@ -403,7 +428,9 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(SlotPtrs s, int32_t h) {
 }
 
 // generic path: local id of every edge position (sorted afterwards by hipcub)
-__global__ __launch_bounds__(kNT) void k_hop_lids_generic(SlotPtrs s, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                           int32_t h) {
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t E = s.st->E[h];
   const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
   if (p >= E) return;
@@ -439,8 +466,9 @@ using namespace spp;
 
 struct SlotHost {
   SlotPtrs p{};
-  hipEvent_t done = nullptr;
-  SlotState* host_state = nullptr;  // pinned
+  hipEvent_t done = nullptr;        // own event object
+  hipEvent_t wait_on = nullptr;     // event that marks this slot's batch complete (group leader's)
+  SlotState* host_state = nullptr;  // into the pinned mirror array
   bool sampled = false;
   bool waited = false;
   int64_t ecap_dyn[SPP_MAX_HOPS];   // current capacity of out_col[h]
@@ -455,10 +483,15 @@ struct spp_sampler {
   int64_t ecap[SPP_MAX_HOPS];
   int64_t dcap = 0;
   bool generic[SPP_MAX_HOPS];
+  bool any_generic = false;
   uint32_t tab_size = 0;
   int64_t bytes = 0;
   std::vector<SlotHost> slots;
   std::vector<void*> allocs;
+  SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
+  SlotState* d_states = nullptr;     // contiguous device states
+  SlotState* h_states = nullptr;     // pinned mirror
+  unsigned long long* tables = nullptr;  // contiguous node tables (slot-major)
 };
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -466,6 +499,12 @@ static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
   SPP_HIP_TRY(hipMalloc(out, bytes));
   s->allocs.push_back(*out);
   s->bytes += (int64_t)bytes;
+  return SPP_OK;
+}
+
+static spp_status upload_slot(spp_sampler* s, int slot, hipStream_t st) {
+  SPP_HIP_TRY(hipMemcpyAsync(s->d_slots + slot, &s->slots[slot].p, sizeof(SlotPtrs), hipMemcpyHostToDevice, st));
+  SPP_HIP_TRY(hipStreamSynchronize(st));
   return SPP_OK;
 }
 
@@ -490,6 +529,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   for (int h = 0; h < H; ++h) {
     const int64_t f = cfg->sizes[h];
     s->generic[h] = (f < 0 || f > kFastMaxFanout);
+    s->any_generic |= s->generic[h];
     if (f >= 0) {
       s->ecap[h] = s->tcap[h] * f;
       s->tcap[h + 1] = std::min(s->tcap[h] * (1 + f), node_bound);
@@ -502,17 +542,39 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     etmp = std::max(etmp, s->ecap[h]);
   }
   const int64_t ucap = s->tcap[H];
-  SPP_REQUIRE(ucap + etmp < (1ll << 31), "spp_sampler_create: batch too large for 32-bit positions");
+  if (ucap + etmp >= (1ll << 31)) {
+    set_error("spp_sampler_create: batch too large for 32-bit positions");
+    delete s;
+    return SPP_ERR_INVALID;
+  }
   uint32_t tab = 1024;
   while ((int64_t)tab < 2 * ucap) tab <<= 1;
   s->tab_size = tab;
   int64_t tmax = 0;
   for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
   const int64_t nblk_max = std::max(ceil_div(tmax, kNT), ceil_div(etmp, kNT)) + 1;
+  const int nslots = cfg->num_slots;
 
-  s->slots.resize(cfg->num_slots);
+  s->slots.resize(nslots);
   spp_status rc = SPP_OK;
-  for (auto& sl : s->slots) {
+  void* v = nullptr;
+  rc = dev_alloc(s, &v, sizeof(SlotPtrs) * (size_t)nslots);
+  s->d_slots = static_cast<SlotPtrs*>(v);
+  if (rc == SPP_OK) {
+    rc = dev_alloc(s, &v, sizeof(SlotState) * (size_t)nslots);
+    s->d_states = static_cast<SlotState*>(v);
+  }
+  if (rc == SPP_OK) {
+    rc = dev_alloc(s, &v, sizeof(unsigned long long) * (size_t)tab * (size_t)nslots);
+    s->tables = static_cast<unsigned long long*>(v);
+  }
+  if (rc == SPP_OK && hipHostMalloc((void**)&s->h_states, sizeof(SlotState) * (size_t)nslots, hipHostMallocDefault) !=
+                          hipSuccess) {
+    set_error("spp_sampler_create: hipHostMalloc failed");
+    rc = SPP_ERR_HIP;
+  }
+  for (int i = 0; i < nslots && rc == SPP_OK; ++i) {
+    SlotHost& sl = s->slots[i];
     SlotPtrs& p = sl.p;
 #define A(ptr, type, count)                                                              \
   if (rc == SPP_OK) {                                                                    \
@@ -523,24 +585,24 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     A(p.n_ids, int32_t, ucap);
     A(p.deg, int32_t, tmax);
     A(p.rowstart, int64_t, tmax);
-    A(p.table, unsigned long long, tab);
-    A(p.rng, uint32_t, s->dcap + kMtSlack);
-    A(p.mt_ring, uint32_t, kMtRing);
+    A(p.rng[0], uint32_t, s->dcap + kMtSlack);
+    A(p.rng[1], uint32_t, s->dcap + kMtSlack);
     A(p.bsum0, int32_t, nblk_max);
     A(p.bsum1, int32_t, nblk_max);
-    A(p.st, SlotState, 1);
     for (int h = 0; h < H; ++h) {
       A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
       A(p.out_col[h], int32_t, s->ecap[h]);
       sl.ecap_dyn[h] = s->ecap[h];
     }
 #undef A
+    p.table = s->tables + (size_t)i * tab;
     p.tab_mask = tab - 1;
+    p.st = s->d_states + i;
+    sl.host_state = s->h_states + i;
     // per-edge temporaries are separately allocated so the generic path can grow them
     if (rc == SPP_OK) {
       sl.etmp_cap = etmp;
-      hipError_t e = hipSuccess;
-      e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
+      hipError_t e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.eslot, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.erank, sizeof(int32_t) * (size_t)etmp);
@@ -554,11 +616,14 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       set_error("spp_sampler_create: hipEventCreate failed");
       rc = SPP_ERR_HIP;
     }
-    if (rc == SPP_OK && hipHostMalloc((void**)&sl.host_state, sizeof(SlotState), hipHostMallocDefault) != hipSuccess) {
-      set_error("spp_sampler_create: hipHostMalloc failed");
+  }
+  if (rc == SPP_OK) {
+    std::vector<SlotPtrs> tmp((size_t)nslots);
+    for (int i = 0; i < nslots; ++i) tmp[(size_t)i] = s->slots[(size_t)i].p;
+    if (hipMemcpy(s->d_slots, tmp.data(), sizeof(SlotPtrs) * (size_t)nslots, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("spp_sampler_create: upload of the slot table failed");
       rc = SPP_ERR_HIP;
     }
-    if (rc != SPP_OK) break;
   }
   if (rc != SPP_OK) {
     spp_sampler_destroy(s);
@@ -574,13 +639,13 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   (void)hipDeviceSynchronize();
   for (auto& sl : s->slots) {
     if (sl.done) (void)hipEventDestroy(sl.done);
-    if (sl.host_state) (void)hipHostFree(sl.host_state);
     if (sl.p.cval) (void)hipFree(sl.p.cval);
     if (sl.p.eslot) (void)hipFree(sl.p.eslot);
     if (sl.p.evals) (void)hipFree(sl.p.evals);
     if (sl.p.erank) (void)hipFree(sl.p.erank);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
+  if (s->h_states) (void)hipHostFree(s->h_states);
   for (void* a : s->allocs) (void)hipFree(a);
   delete s;
 }
@@ -593,8 +658,10 @@ extern "C" spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg*
   return SPP_OK;
 }
 
-static spp_status grow_edge_scratch(spp_sampler* s, SlotHost& sl, int h, int64_t need) {
+static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t need, hipStream_t st) {
   // generic path only; the stream has been synchronised by the caller
+  SlotHost& sl = s->slots[(size_t)slot];
+  bool changed = false;
   if (need > sl.etmp_cap) {
     int64_t cap = std::max(need, sl.etmp_cap * 2);
     (void)hipFree(sl.p.cval); (void)hipFree(sl.p.eslot); (void)hipFree(sl.p.evals); (void)hipFree(sl.p.erank);
@@ -605,6 +672,7 @@ static spp_status grow_edge_scratch(spp_sampler* s, SlotHost& sl, int h, int64_t
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.erank, sizeof(int32_t) * (size_t)cap));
     s->bytes += 16 * (cap - sl.etmp_cap);
     sl.etmp_cap = cap;
+    changed = true;
   }
   if (need > sl.ecap_dyn[h]) {
     int64_t cap = std::max(need, sl.ecap_dyn[h] * 2);
@@ -614,84 +682,137 @@ static spp_status grow_edge_scratch(spp_sampler* s, SlotHost& sl, int h, int64_t
     sl.p.out_col[h] = static_cast<int32_t*>(v);
     s->bytes += 4 * cap;
     sl.ecap_dyn[h] = cap;
+    changed = true;
+  }
+  if (changed) SPP_TRY(upload_slot(s, slot, st));
+  return SPP_OK;
+}
+
+namespace spp {
+
+int sampler_max_group(const spp_sampler* s) { return s->any_generic ? 1 : kMaxGroup; }
+
+// mt19937 streams of a group of batches into rng[buf] of their slots
+spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, const uint32_t* seeds,
+                              const int64_t* skips, hipStream_t st) {
+  if (s->dcap <= 0) return SPP_OK;
+  GroupArgs ga{};
+  ga.first_slot = first_slot;
+  ga.n = n;
+  ga.rng_buf = buf;
+  for (int i = 0; i < n; ++i) {
+    ga.rng_seed[i] = seeds[i];
+    ga.rng_skip[i] = skips ? skips[i] : 0;
+  }
+  hipLaunchKernelGGL(k_rng_fill, dim3(1, (unsigned)n), dim3(kMtThreads), 0, st, s->d_slots, ga, s->dcap);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+// sampling chain of a group of batches (RNG already in rng[buf]); records the group's completion event
+spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
+                                const int64_t* n_seeds, hipStream_t st) {
+  SPP_REQUIRE(n >= 1 && n <= sampler_max_group(s), "sampler_launch_chain: group of %d batches not supported", n);
+  SPP_REQUIRE(first_slot >= 0 && first_slot + n <= (int)s->slots.size(), "sampler_launch_chain: slots out of range");
+  const int H = s->cfg.num_hops;
+  const int64_t* rowptr = s->cfg.rowptr_dev;
+  const int64_t* col = s->cfg.col_dev;
+  const int32_t replace = s->cfg.replace ? 1 : 0;
+  GroupArgs ga{};
+  ga.first_slot = first_slot;
+  ga.n = n;
+  ga.rng_buf = buf;
+  int64_t max_seeds = 1;
+  for (int i = 0; i < n; ++i) {
+    SPP_REQUIRE(n_seeds[i] >= 0 && n_seeds[i] <= s->cfg.max_batch, "spp_sampler: n_seeds %lld exceeds max_batch %lld",
+                (long long)n_seeds[i], (long long)s->cfg.max_batch);
+    SPP_REQUIRE(seeds_dev[i] || n_seeds[i] == 0, "spp_sampler: seeds_dev is NULL");
+    ga.seeds[i] = seeds_dev[i];
+    ga.n_seeds[i] = (int32_t)n_seeds[i];
+    max_seeds = std::max(max_seeds, n_seeds[i]);
+  }
+  const unsigned gy = (unsigned)n;
+  SlotHost& lead = s->slots[(size_t)first_slot];
+
+  SPP_HIP_TRY(hipMemsetAsync(lead.p.table, 0xFF, sizeof(unsigned long long) * (size_t)s->tab_size * (size_t)n, st));
+  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)ceil_div(max_seeds, kNT), gy), dim3(kNT), 0, st, s->d_slots, ga);
+  for (int h = 0; h < H; ++h) {
+    const int32_t f = (int32_t)s->cfg.sizes[h];
+    const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
+    hipLaunchKernelGGL(k_hop_count, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, rowptr, h, f, replace);
+    // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
+    const int32_t ecap_dev =
+        s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(lead.ecap_dyn[h], 0x7fffffff);
+    hipLaunchKernelGGL(k_hop_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f, ecap_dev, s->dcap);
+    unsigned ge;
+    if (!s->generic[h]) {
+      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col, h, f,
+                         replace);
+      ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
+    } else {
+      // slow path (n == 1): the edge count is needed on the host to size launches and scratch
+      SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState), hipMemcpyDeviceToHost, st));
+      SPP_HIP_TRY(hipStreamSynchronize(st));
+      const int64_t E = lead.host_state->E[h];
+      if (lead.host_state->error) break;
+      SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
+      ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
+      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col, h, f,
+                         replace);
+      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h, f,
+                         replace);
+    }
+    hipLaunchKernelGGL(k_hop_flag, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+    hipLaunchKernelGGL(k_hop_scan2, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f,
+                       (int32_t)s->tcap[H]);
+    hipLaunchKernelGGL(k_hop_assign, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+    if (!s->generic[h]) {
+      hipLaunchKernelGGL(k_hop_rows, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+    } else {
+      const int64_t E = lead.host_state->E[h];
+      const int32_t T = lead.host_state->cnt[h];
+      if (E > 0) {
+        hipLaunchKernelGGL(k_hop_lids_generic, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+        size_t need = 0;
+        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, lead.p.cval, lead.p.out_col[h], (int)E, T,
+                                                               lead.p.out_rowptr[h], lead.p.out_rowptr[h] + 1, 0, 32,
+                                                               st));
+        if (need > lead.cub_tmp_bytes) {
+          SPP_HIP_TRY(hipStreamSynchronize(st));
+          if (lead.cub_tmp) (void)hipFree(lead.cub_tmp);
+          lead.cub_tmp = nullptr;
+          SPP_HIP_TRY(hipMalloc(&lead.cub_tmp, need));
+          lead.cub_tmp_bytes = need;
+        }
+        size_t have = lead.cub_tmp_bytes;
+        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(lead.cub_tmp, have, lead.p.cval, lead.p.out_col[h],
+                                                               (int)E, T, lead.p.out_rowptr[h],
+                                                               lead.p.out_rowptr[h] + 1, 0, 32, st));
+      }
+    }
+  }
+  SPP_HIP_TRY(hipGetLastError());
+  SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState) * (size_t)n, hipMemcpyDeviceToHost, st));
+  SPP_HIP_TRY(hipEventRecord(lead.done, st));
+  for (int i = 0; i < n; ++i) {
+    SlotHost& sl = s->slots[(size_t)(first_slot + i)];
+    sl.wait_on = lead.done;
+    sl.sampled = true;
+    sl.waited = false;
   }
   return SPP_OK;
 }
+
+}  // namespace spp
 
 extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int64_t* seeds_dev, int64_t n_seeds,
                                          uint32_t rng_seed, int64_t rng_skip, void* stream) {
   SPP_REQUIRE(s, "spp_sampler_sample: NULL sampler");
   SPP_REQUIRE(slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_sample: slot %d out of range", slot);
-  SPP_REQUIRE(n_seeds >= 0 && n_seeds <= s->cfg.max_batch, "spp_sampler_sample: n_seeds %lld exceeds max_batch %lld",
-              (long long)n_seeds, (long long)s->cfg.max_batch);
-  SPP_REQUIRE(seeds_dev || n_seeds == 0, "spp_sampler_sample: seeds_dev is NULL");
   SPP_REQUIRE(rng_skip >= 0, "spp_sampler_sample: rng_skip must be >= 0");
-  SlotHost& sl = s->slots[slot];
   hipStream_t st = as_stream(stream);
-  const int H = s->cfg.num_hops;
-  const int64_t* rowptr = s->cfg.rowptr_dev;
-  const int64_t* col = s->cfg.col_dev;
-  const int32_t replace = s->cfg.replace ? 1 : 0;
-
-  SPP_HIP_TRY(hipMemsetAsync(sl.p.table, 0xFF, sizeof(unsigned long long) * (size_t)s->tab_size, st));
-  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)std::max<int64_t>(1, ceil_div(n_seeds, kNT))), dim3(kNT), 0, st, sl.p,
-                     seeds_dev, (int32_t)n_seeds, rng_skip);
-  for (int h = 0; h < H; ++h) {
-    const int32_t f = (int32_t)s->cfg.sizes[h];
-    const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
-    hipLaunchKernelGGL(k_hop_count, dim3(gt), dim3(kNT), 0, st, sl.p, rowptr, h, f, replace);
-    // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
-    const int32_t ecap_dev = s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(sl.ecap_dyn[h], 0x7fffffff);
-    hipLaunchKernelGGL(k_hop_scan, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, ecap_dev);
-    if (f > 0)
-      hipLaunchKernelGGL(k_mt_advance, dim3(1), dim3(kMtThreads), 0, st, sl.p, h, f, rng_seed, rng_skip, s->dcap);
-    unsigned ge;
-    if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f, replace);
-      ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
-    } else {
-      // slow path: the edge count is needed on the host to size launches and scratch
-      SPP_HIP_TRY(hipMemcpyAsync(sl.host_state, sl.p.st, sizeof(SlotState), hipMemcpyDeviceToHost, st));
-      SPP_HIP_TRY(hipStreamSynchronize(st));
-      const int64_t E = sl.host_state->E[h];
-      if (sl.host_state->error) break;
-      SPP_TRY(grow_edge_scratch(s, sl, h, E));
-      ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt), dim3(kNT), 0, st, sl.p, col, h, f, replace);
-      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge), dim3(kNT), 0, st, sl.p, col, h, f, replace);
-    }
-    hipLaunchKernelGGL(k_hop_flag, dim3(ge), dim3(kNT), 0, st, sl.p, h);
-    hipLaunchKernelGGL(k_hop_scan2, dim3(1), dim3(kScanNT), 0, st, sl.p, h, f, (int32_t)s->tcap[H]);
-    hipLaunchKernelGGL(k_hop_assign, dim3(ge), dim3(kNT), 0, st, sl.p, h);
-    if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_rows, dim3(gt), dim3(kNT), 0, st, sl.p, h);
-    } else {
-      const int64_t E = sl.host_state->E[h];
-      const int32_t T = sl.host_state->cnt[h];
-      if (E > 0) {
-        hipLaunchKernelGGL(k_hop_lids_generic, dim3(ge), dim3(kNT), 0, st, sl.p, h);
-        size_t need = 0;
-        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, sl.p.cval, sl.p.out_col[h], (int)E, T,
-                                                               sl.p.out_rowptr[h], sl.p.out_rowptr[h] + 1, 0, 32, st));
-        if (need > sl.cub_tmp_bytes) {
-          SPP_HIP_TRY(hipStreamSynchronize(st));
-          if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
-          sl.cub_tmp = nullptr;
-          SPP_HIP_TRY(hipMalloc(&sl.cub_tmp, need));
-          sl.cub_tmp_bytes = need;
-        }
-        size_t have = sl.cub_tmp_bytes;
-        SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(sl.cub_tmp, have, sl.p.cval, sl.p.out_col[h], (int)E, T,
-                                                               sl.p.out_rowptr[h], sl.p.out_rowptr[h] + 1, 0, 32, st));
-      }
-    }
-  }
-  SPP_HIP_TRY(hipGetLastError());
-  SPP_HIP_TRY(hipMemcpyAsync(sl.host_state, sl.p.st, sizeof(SlotState), hipMemcpyDeviceToHost, st));
-  SPP_HIP_TRY(hipEventRecord(sl.done, st));
-  sl.sampled = true;
-  sl.waited = false;
-  return SPP_OK;
+  SPP_TRY(sampler_launch_rng(s, slot, 1, 0, &rng_seed, &rng_skip, st));
+  return sampler_launch_chain(s, slot, 1, 0, &seeds_dev, &n_seeds, st);
 }
 
 static void fill_counts(const spp_sampler* s, const SlotState* hs, spp_mfg_counts* out) {
@@ -715,7 +836,7 @@ extern "C" spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_cou
     set_error("spp_sampler_wait: slot %d has no batch in flight", slot);
     return SPP_ERR_STATE;
   }
-  SPP_HIP_TRY(hipEventSynchronize(sl.done));
+  SPP_HIP_TRY(hipEventSynchronize(sl.wait_on));
   sl.waited = true;
   if (sl.host_state->error) {
     set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws)",

@@ -1,0 +1,23 @@
+// Internal (non-ABI) interface between sampler.hip and session.hip: grouped launches.
+#pragma once
+
+#include "spp_internal.h"
+
+namespace spp {
+
+constexpr int kMaxGroup = 16;  // batches one launch can process (blockIdx.y)
+
+// largest group the sampler supports (1 when a hop takes the generic path)
+int sampler_max_group(const spp_sampler* s);
+
+// Generate the mt19937 streams of `n` batches (slots first_slot..first_slot+n-1) into RNG buffer
+// `buf` (0/1) of their slots: draws [skip, skip + Dcap) of mt19937(seed).
+spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, const uint32_t* seeds,
+                              const int64_t* skips, hipStream_t st);
+
+// Enqueue the sampling chain of `n` batches whose RNG streams are in buffer `buf`; records the
+// group's completion event (spp_sampler_wait on any slot of the group waits for it).
+spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
+                                const int64_t* n_seeds, hipStream_t st);
+
+}  // namespace spp

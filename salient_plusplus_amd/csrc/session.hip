@@ -1,8 +1,8 @@
 // a6/a7: Session runtime.  Replaces the reference's CPU worker pool (global ThreadPool,
 // fast_sampler.cpp:398-453), per-epoch FastSamplerSession (:533-936), MPMC queues and the
-// `items_in_queue` semaphore with `max_items_in_queue` batch slots kept in flight on a few HIP
-// streams: producers are GPU streams, back-pressure is slot reuse, and the consumer only ever
-// blocks on a HIP event.  Python-visible semantics are preserved:
+// `items_in_queue` semaphore with batch slots kept in flight on HIP streams: producers are GPU
+// streams, back-pressure is slot reuse, and the consumer only ever blocks on a HIP event.
+// Python-visible semantics are preserved:
 //   * batch ranges: fast_sampler.cpp:587-627 (plain / skip_nonfull / exact-count split);
 //   * per-batch generator seed: gen.seed(range.second*17+5)  (fast_sampler.cpp:994);
 //   * worker body (non-distributed): multilayer_sample -> x = x[n_id], y = y[n_id[:bs]]
@@ -10,11 +10,20 @@
 //   * end of data is signalled by "no batch" (the reference returns None).
 // Batches are delivered in index order (a valid completion order for the non-distributed path and
 // the required order for the distributed one, fast_sampler.cpp:672-711).
+//
+// Scheduling.  Consecutive batches are sampled in GROUPS of G (one launch sequence per group, see
+// sampler.hip); the `max_items_in_queue` slots form max_items/G slot-sets, each with its own HIP
+// stream.  The mt19937 streams of a group are generated one slot-set generation AHEAD on a separate
+// stream into the idle half of a per-slot ping-pong buffer, so the serial generator never delays a
+// sampling chain.  When the last batch of a group has been exported, its slot-set immediately
+// starts the next pending group (ordered after the consumer's copies by events).
 #include "spp_internal.h"
 
 #include <chrono>
 #include <utility>
 #include <vector>
+
+#include "sampler_internal.h"
 
 using namespace spp;
 
@@ -23,12 +32,20 @@ struct spp_session {
   spp_sampler* sampler = nullptr;
   bool owns_sampler = true;
   std::vector<std::pair<int32_t, int32_t>> ranges;
-  std::vector<hipStream_t> streams;
-  std::vector<hipEvent_t> export_done;  // per slot
-  int32_t num_slots = 0;
-  int64_t next_to_launch = 0;
-  int64_t next_to_deliver = 0;
-  int32_t current_slot = -1;  // delivered by next(), not yet exported/recycled
+  int G = 1;                 // batches per group
+  int num_sets = 1;          // slot-sets in flight
+  int64_t num_groups = 0;    // groups in this epoch
+  std::vector<hipStream_t> streams;      // one per slot-set
+  hipStream_t rng_stream = nullptr;
+  std::vector<hipEvent_t> rng_done;      // [set*2 + buf]
+  std::vector<hipEvent_t> chain_done;    // [set*2 + buf]
+  std::vector<char> chain_recorded;      // [set*2 + buf]
+  std::vector<hipEvent_t> export_done;   // per slot
+  std::vector<char> export_recorded;     // per slot
+  int64_t rng_launched = 0;              // groups whose RNG streams were launched
+  int64_t chain_launched = 0;            // groups whose sampling chain was launched
+  int64_t next_to_deliver = 0;           // batch index
+  int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
   int64_t blocked_us = 0;
   int64_t blocked_occasions = 0;
 };
@@ -67,21 +84,66 @@ static void build_ranges(const spp_session_cfg& c, std::vector<std::pair<int32_t
   }
 }
 
-static spp_status launch_batch(spp_session* s, int64_t b, int32_t slot) {
-  const auto& r = s->ranges[(size_t)b];
-  hipStream_t st = s->streams[(size_t)slot % s->streams.size()];
-  return spp_sampler_sample(s->sampler, slot, s->cfg.idx_dev + r.first, (int64_t)r.second - r.first,
-                            spp_batch_seed(r.second), 0, st);
+static inline int group_len(const spp_session* s, int64_t g) {
+  const int64_t nb = (int64_t)s->ranges.size();
+  return (int)std::min<int64_t>(s->G, nb - g * s->G);
 }
 
-// hand `slot` back: the next pending batch starts sampling into it, ordered after `after` (an event
-// recorded on the consumer's stream once its copies out of the slot were enqueued), if any
-static spp_status recycle_slot(spp_session* s, int32_t slot, hipEvent_t after) {
-  if (s->next_to_launch < (int64_t)s->ranges.size()) {
-    hipStream_t st = s->streams[(size_t)slot % s->streams.size()];
-    if (after) SPP_HIP_TRY(hipStreamWaitEvent(st, after, 0));
-    SPP_TRY(launch_batch(s, s->next_to_launch, slot));
-    s->next_to_launch++;
+static spp_status launch_group_rng(spp_session* s, int64_t g) {
+  const int set = (int)(g % s->num_sets);
+  const int buf = (int)((g / s->num_sets) & 1);
+  const int n = group_len(s, g);
+  uint32_t seeds[kMaxGroup];
+  for (int i = 0; i < n; ++i) seeds[i] = spp_batch_seed(s->ranges[(size_t)(g * s->G + i)].second);  // :994
+  // the previous user of this RNG buffer (group g - 2*num_sets) must have finished sampling
+  if (s->chain_recorded[(size_t)(set * 2 + buf)])
+    SPP_HIP_TRY(hipStreamWaitEvent(s->rng_stream, s->chain_done[(size_t)(set * 2 + buf)], 0));
+  SPP_TRY(sampler_launch_rng(s->sampler, set * s->G, n, buf, seeds, nullptr, s->rng_stream));
+  SPP_HIP_TRY(hipEventRecord(s->rng_done[(size_t)(set * 2 + buf)], s->rng_stream));
+  return SPP_OK;
+}
+
+static spp_status launch_group_chain(spp_session* s, int64_t g) {
+  const int set = (int)(g % s->num_sets);
+  const int buf = (int)((g / s->num_sets) & 1);
+  const int n = group_len(s, g);
+  hipStream_t st = s->streams[(size_t)set];
+  const int64_t* seeds[kMaxGroup];
+  int64_t n_seeds[kMaxGroup];
+  for (int i = 0; i < n; ++i) {
+    const auto& r = s->ranges[(size_t)(g * s->G + i)];
+    seeds[i] = s->cfg.idx_dev + r.first;
+    n_seeds[i] = (int64_t)r.second - r.first;
+  }
+  SPP_HIP_TRY(hipStreamWaitEvent(st, s->rng_done[(size_t)(set * 2 + buf)], 0));
+  // the consumer's copies out of these slots (previous group of this slot-set) must be done
+  for (int i = 0; i < s->G; ++i) {
+    const size_t slot = (size_t)(set * s->G + i);
+    if (s->export_recorded[slot]) {
+      SPP_HIP_TRY(hipStreamWaitEvent(st, s->export_done[slot], 0));
+      s->export_recorded[slot] = 0;
+    }
+  }
+  SPP_TRY(sampler_launch_chain(s->sampler, set * s->G, n, buf, seeds, n_seeds, st));
+  SPP_HIP_TRY(hipEventRecord(s->chain_done[(size_t)(set * 2 + buf)], st));
+  s->chain_recorded[(size_t)(set * 2 + buf)] = 1;
+  return SPP_OK;
+}
+
+// keep the pipeline full: chains for up to num_sets groups beyond the ones fully consumed, RNG one
+// slot-set generation further
+static spp_status pump(spp_session* s, int64_t groups_fully_consumed) {
+  while (s->chain_launched < s->num_groups && s->chain_launched < groups_fully_consumed + s->num_sets) {
+    if (s->rng_launched <= s->chain_launched) {
+      SPP_TRY(launch_group_rng(s, s->rng_launched));
+      s->rng_launched++;
+    }
+    SPP_TRY(launch_group_chain(s, s->chain_launched));
+    s->chain_launched++;
+  }
+  while (s->rng_launched < s->num_groups && s->rng_launched < s->chain_launched + s->num_sets) {
+    SPP_TRY(launch_group_rng(s, s->rng_launched));
+    s->rng_launched++;
   }
   return SPP_OK;
 }
@@ -101,14 +163,22 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   int64_t max_batch = 1;
   for (auto& r : s->ranges) max_batch = std::max<int64_t>(max_batch, r.second - r.first);
   const int64_t nb = (int64_t)s->ranges.size();
-  s->num_slots = (int32_t)std::max<int64_t>(1, std::min<int64_t>(cfg->max_items_in_queue, nb));
+  const int M = (int)std::max<int64_t>(1, std::min<int64_t>(cfg->max_items_in_queue, std::max<int64_t>(nb, 1)));
+
+  bool generic = false;
+  for (int h = 0; h < cfg->num_hops; ++h) generic |= (cfg->sizes[h] < 0 || cfg->sizes[h] > 32);
+  int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 3));
+  G = std::min(G, std::min(M, kMaxGroup));
+  if (generic) G = 1;
+  int sets = std::max(1, M / G);
 
   spp_status rc = SPP_OK;
   if (cfg->sampler) {
     spp_sampler_cfg have{};
     rc = spp_sampler_get_cfg(cfg->sampler, &have);
     bool ok = rc == SPP_OK && have.rowptr_dev == cfg->rowptr_dev && have.col_dev == cfg->col_dev &&
-              have.num_hops == cfg->num_hops && have.max_batch >= max_batch && have.device == cfg->device && have.replace == 0;
+              have.num_hops == cfg->num_hops && have.max_batch >= max_batch && have.device == cfg->device &&
+              have.replace == 0 && have.num_slots >= 1;
     for (int h = 0; ok && h < cfg->num_hops; ++h) ok = have.sizes[h] == cfg->sizes[h];
     if (!ok) {
       set_error("spp_session_create: borrowed sampler is not compatible with this session's graph/fanouts/batch");
@@ -117,7 +187,8 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
     }
     s->sampler = cfg->sampler;
     s->owns_sampler = false;
-    s->num_slots = std::min<int32_t>(s->num_slots, have.num_slots);
+    G = std::min(G, have.num_slots);
+    sets = std::max(1, std::min(sets, have.num_slots / G));
   } else {
     spp_sampler_cfg sc{};
     sc.rowptr_dev = cfg->rowptr_dev;
@@ -127,7 +198,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
     sc.num_hops = cfg->num_hops;
     for (int h = 0; h < SPP_MAX_HOPS; ++h) sc.sizes[h] = cfg->sizes[h];
     sc.max_batch = max_batch;
-    sc.num_slots = s->num_slots;
+    sc.num_slots = G * sets;
     sc.device = cfg->device;
     rc = spp_sampler_create(&sc, &s->sampler);
     if (rc != SPP_OK) {
@@ -135,31 +206,34 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
       return rc;
     }
   }
-  int nstreams = cfg->num_streams > 0 ? cfg->num_streams : 4;
-  nstreams = std::min(nstreams, (int)s->num_slots);
-  for (int i = 0; i < nstreams && rc == SPP_OK; ++i) {
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-      set_error("spp_session_create: hipStreamCreate failed");
-      rc = SPP_ERR_HIP;
-    } else {
-      s->streams.push_back(st);
-    }
-  }
-  for (int i = 0; i < s->num_slots && rc == SPP_OK; ++i) {
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+  s->G = G;
+  s->num_sets = sets;
+  s->num_groups = (nb + G - 1) / G;
+
+  auto mk_event = [&](hipEvent_t* ev) {
+    if (rc == SPP_OK && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) {
       set_error("spp_session_create: hipEventCreate failed");
       rc = SPP_ERR_HIP;
-    } else {
-      s->export_done.push_back(ev);
     }
-  }
-  // prime the pipeline: the first num_slots batches start sampling now
-  for (int i = 0; i < s->num_slots && rc == SPP_OK && s->next_to_launch < nb; ++i) {
-    rc = launch_batch(s, s->next_to_launch, i);
-    if (rc == SPP_OK) s->next_to_launch++;
-  }
+  };
+  auto mk_stream = [&](hipStream_t* st) {
+    if (rc == SPP_OK && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) {
+      set_error("spp_session_create: hipStreamCreate failed");
+      rc = SPP_ERR_HIP;
+    }
+  };
+  s->streams.assign((size_t)sets, nullptr);
+  for (auto& st : s->streams) mk_stream(&st);
+  mk_stream(&s->rng_stream);
+  s->rng_done.assign((size_t)sets * 2, nullptr);
+  s->chain_done.assign((size_t)sets * 2, nullptr);
+  s->chain_recorded.assign((size_t)sets * 2, 0);
+  for (auto& e : s->rng_done) mk_event(&e);
+  for (auto& e : s->chain_done) mk_event(&e);
+  s->export_done.assign((size_t)(sets * G), nullptr);
+  s->export_recorded.assign((size_t)(sets * G), 0);
+  for (auto& e : s->export_done) mk_event(&e);
+  if (rc == SPP_OK) rc = pump(s, 0);  // prime the pipeline
   if (rc != SPP_OK) {
     spp_session_destroy(s);
     return rc;
@@ -171,10 +245,19 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 extern "C" void spp_session_destroy(spp_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->cfg.device);
-  for (auto st : s->streams) (void)hipStreamSynchronize(st);
+  for (auto st : s->streams)
+    if (st) (void)hipStreamSynchronize(st);
+  if (s->rng_stream) (void)hipStreamSynchronize(s->rng_stream);
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
-  for (auto ev : s->export_done) (void)hipEventDestroy(ev);
-  for (auto st : s->streams) (void)hipStreamDestroy(st);
+  for (auto ev : s->rng_done)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto ev : s->chain_done)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto ev : s->export_done)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto st : s->streams)
+    if (st) (void)hipStreamDestroy(st);
+  if (s->rng_stream) (void)hipStreamDestroy(s->rng_stream);
   delete s;
 }
 
@@ -193,19 +276,30 @@ extern "C" spp_status spp_session_batch_ranges(const spp_session* s, int32_t* ou
   return SPP_OK;
 }
 
+// the batch in `current_slot` is done with (exported or dropped): recycle its slot-set once the
+// whole group has been consumed
+static spp_status retire_current(spp_session* s) {
+  const int64_t b = s->next_to_deliver - 1;
+  s->current_slot = -1;
+  const int64_t g = b / s->G;
+  const bool last_of_group = (b + 1 == (int64_t)s->ranges.size()) || ((b + 1) % s->G == 0);
+  if (last_of_group) return pump(s, g + 1);
+  return SPP_OK;
+}
+
 extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   if (!s || !out) {
     set_error("spp_session_next: NULL argument");
     return SPP_ERR_INVALID;
   }
-  if (s->current_slot >= 0) {  // previous batch was never exported: drop it and reuse its slot
-    spp_status rc = recycle_slot(s, s->current_slot, nullptr);
-    s->current_slot = -1;
+  if (s->current_slot >= 0) {  // previous batch was never exported: drop it
+    spp_status rc = retire_current(s);
     if (rc != SPP_OK) return rc;
   }
   if (s->next_to_deliver == (int64_t)s->ranges.size()) return 0;  // blocking_get_batch -> None
   const int64_t b = s->next_to_deliver;
-  const int32_t slot = (int32_t)(b % s->num_slots);
+  const int64_t g = b / s->G;
+  const int32_t slot = (int32_t)((g % s->num_sets) * s->G + b % s->G);
   const auto t0 = std::chrono::steady_clock::now();
   spp_status rc = spp_sampler_wait(s->sampler, slot, &out->counts);
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -240,6 +334,6 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   if (y_src_dev && y_out_dev)  // y_s = serial_index(y, n_id, batch_size) (fast_sampler.cpp:1009)
     SPP_TRY(spp_sampler_gather(s->sampler, slot, y_src_dev, y_rows, y_row_bytes, bs, y_out_dev, stream));
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
-  s->current_slot = -1;
-  return recycle_slot(s, slot, s->export_done[(size_t)slot]);
+  s->export_recorded[(size_t)slot] = 1;
+  return retire_current(s);
 }

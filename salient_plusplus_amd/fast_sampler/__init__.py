@@ -29,7 +29,7 @@ from .. import _native as nat
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
            "multilayer_sample", "full_sample", "to_row_major", "serial_index"]
 
-_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "8"))
+_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "24"))
 
 
 # --------------------------------------------------------------------------------------------
@@ -359,7 +359,7 @@ class Session:
         cfg.force_exact_num_batches = int(force_exact)
         cfg.exact_num_batches = int(config.exact_num_batches)
         cfg.max_items_in_queue = slots
-        cfg.num_streams = max(1, min(int(num_threads), 4))
+        cfg.group_size = int(os.environ.get("SPP_GROUP_SIZE", "0"))   # 0 = auto
         cfg.device = self._dev.index
         cfg.sampler = self._pool_entry[0]
         h = C.c_void_p()
