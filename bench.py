@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
 
 
@@ -146,8 +148,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the MI355X data path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or a.force_distributed
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from salient_plusplus_amd import _native as nat
@@ -167,7 +171,7 @@ def main():
     sizes, bs = wl.fanouts, wl.batch_size
     y2 = wl.y.unsqueeze(-1)
 
-    if world == 1:
+    if not distributed:
         n_train = wl.train_idx.numel()
         cfg = FastSamplerConfig(
             x_cpu=wl.x, x_gpu=torch.empty(0), y=y2, rowptr=wl.rowptr, col=wl.col,
@@ -194,7 +198,7 @@ def main():
         deg = wl.rowptr[1:] - wl.rowptr[:-1]
         deg_remote = deg.clone()
         deg_remote[lo:hi] = -1
-        n_cache = int(a.cache_frac * N / world)
+        n_cache = int(a.cache_frac * N / world) if world > 1 else 0
         cached_vertices = torch.topk(deg_remote, n_cache).indices.sort().values if n_cache > 0 \
             else torch.empty(0, dtype=torch.int64, device=dev)
         cache = fs.Cache(rank, world, cached_vertices, wl.x[cached_vertices].contiguous()) if n_cache > 0 \
@@ -221,7 +225,7 @@ def main():
     for _ in range(a.warmup):
         feeder.next()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     L.spp_profile_enable(1)
@@ -232,18 +236,18 @@ def main():
         edges += count_edges(b)
         nodes += b.x.size(0)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # gather-kernel time, measured live with HIP events on the launching stream
     ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
-    prof_kind = 0 if world == 1 else 1      # SPP_PROF_GATHER / SPP_PROF_ASSEMBLE
+    prof_kind = 1 if distributed else 0      # SPP_PROF_ASSEMBLE / SPP_PROF_GATHER
     nat.check(L.spp_profile_read(prof_kind, C.byref(ms), C.byref(n_launch), C.byref(rows)))
     L.spp_profile_enable(0)
 
     stats = torch.tensor([dt, float(edges), float(nodes)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         tmax = stats[0:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = stats[1:].clone()
@@ -256,11 +260,11 @@ def main():
         alg_bytes_per_row = 2 * row_bytes + 8          # read row + write row + int64 index
         # N == 1: every step launches the x gather and the (tiny) label gather; the label rows are
         # taken out of the row count, their ~2 us launches stay in the time (conservative).
-        x_rows = rows.value - a.steps * bs if world == 1 else rows.value
+        x_rows = rows.value if distributed else rows.value - a.steps * bs
         x_ms = ms.value
-        launches_x = n_launch.value // 2 if world == 1 else n_launch.value
+        launches_x = n_launch.value if distributed else n_launch.value // 2
         achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_gather_rows" if world == 1 else "k_assemble",
+        roof = {"bound": "hbm", "kernel": "k_assemble" if distributed else "k_gather_rows",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
@@ -274,18 +278,18 @@ def main():
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
             "batches_per_s": a.steps * world / dt,
-            "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if world == 1 else None,
+            "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
             "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),
             "graph_build_s": t_build,
             "roofline": roof,
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and not distributed:
             threads = host_cpu_share()
             host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
             out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
