@@ -269,6 +269,15 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
                 "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
+        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
+        # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
+        pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+        if not distributed and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc["shape"]["row_bytes"] == row_bytes:
+                roof["traffic"] = pmc["traffic_bytes_per_row"] * roof["rows_per_launch"]
+                roof["traffic_source"] = "profiles/r01_gather_pmc.json (bytes/row x rows/launch)"
+                roof["algorithmic_bytes_per_launch"] = alg_bytes_per_row * roof["rows_per_launch"]
         out = {
             "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
