@@ -5,77 +5,32 @@
 // cover one contiguous span of dst, and every group keeps UNROLL independent rows in flight.
 #include "spp_internal.h"
 
+#include "gather_body.cuh"
+
 namespace spp {
-
-template <int VEC> struct vec_of;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <> struct vec_of<16> { using type = u32x4; };
-template <> struct vec_of<8> { using type = u32x2; };
-template <> struct vec_of<4> { using type = uint32_t; };
-template <> struct vec_of<2> { using type = uint16_t; };
-template <> struct vec_of<1> { using type = uint8_t; };
-
-constexpr int kGatherThreads = 256;
-constexpr int kGatherUnroll = 4;
 
 template <int VEC, typename IdxT>
 __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(const char* __restrict__ src,
                                                                  const IdxT* __restrict__ idx, int64_t n,
                                                                  int64_t row_bytes, int chunks, int lpr_log2,
                                                                  char* __restrict__ dst) {
-  using V = typename vec_of<VEC>::type;
-  const int lpr = 1 << lpr_log2;
-  const int g = threadIdx.x >> lpr_log2;
-  const int l = threadIdx.x & (lpr - 1);
-  const int gpb = kGatherThreads >> lpr_log2;  // row groups per workgroup
-  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
-  for (int64_t base = (int64_t)blockIdx.x * rows_per_iter; base < n; base += (int64_t)gridDim.x * rows_per_iter) {
-    const V* s[kGatherUnroll];
-    V* d[kGatherUnroll];
-    bool ok[kGatherUnroll];
-#pragma unroll
-    for (int u = 0; u < kGatherUnroll; ++u) {
-      const int64_t r = base + (int64_t)u * gpb + g;
-      ok[u] = r < n;
-      const int64_t sr = ok[u] ? (int64_t)idx[r] : 0;
-      s[u] = reinterpret_cast<const V*>(src + sr * row_bytes);
-      d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
-    }
-    for (int c = l; c < chunks; c += lpr) {
-      V v[kGatherUnroll];
-#pragma unroll
-      for (int u = 0; u < kGatherUnroll; ++u)
-        if (ok[u]) v[u] = s[u][c];
-#pragma unroll
-      for (int u = 0; u < kGatherUnroll; ++u)
-        if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);
-    }
-  }
+  gather_rows_body<VEC, IdxT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x);
 }
 
 template <typename IdxT>
 static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* idx, int64_t n, void* dst,
                                 hipStream_t st) {
   if (n <= 0 || row_bytes <= 0) return SPP_OK;
-  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)row_bytes;
-  int vec = 16;
-  while (vec > 1 && (a % vec) != 0) vec >>= 1;
-  const int chunks = (int)(row_bytes / vec);
-  int lpr_log2 = 0;
-  while ((1 << lpr_log2) < chunks && lpr_log2 < 6) ++lpr_log2;
-  const int gpb = kGatherThreads >> lpr_log2;
-  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
-  int64_t grid = ceil_div(n, rows_per_iter);
-  const int64_t max_grid = 256 * 16;  // 256 CUs x 16 workgroups: grid-stride beyond that
-  if (grid > max_grid) grid = max_grid;
+  const GatherGeom gg = gather_geometry(src, dst, row_bytes, n);
+  const int chunks = gg.chunks, lpr_log2 = gg.lpr_log2;
+  const int64_t grid = gg.grid;
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
   const int prof = prof_begin(SPP_PROF_GATHER, st, n);
 #define SPP_LAUNCH_GATHER(V)                                                                              \
   hipLaunchKernelGGL((k_gather_rows<V, IdxT>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, idx, n, \
                      row_bytes, chunks, lpr_log2, d)
-  switch (vec) {
+  switch (gg.vec) {
     case 16: SPP_LAUNCH_GATHER(16); break;
     case 8: SPP_LAUNCH_GATHER(8); break;
     case 4: SPP_LAUNCH_GATHER(4); break;

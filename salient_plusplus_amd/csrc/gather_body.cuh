@@ -1,0 +1,84 @@
+// Row-gather inner loop shared by k_gather_rows (gather.hip) and the fused k_deliver (sampler.hip).
+// A group of LPR lanes (power of two) moves one row with VEC-byte accesses; consecutive groups take
+// consecutive output rows so a wavefront's stores cover one contiguous span of dst, and every
+// group keeps kGatherUnroll independent rows in flight.  `vblock`/`nvblocks` are the calling
+// workgroup's index and the number of workgroups that share this gather (grid-stride).
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace spp {
+
+template <int VEC> struct vec_of;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <> struct vec_of<16> { using type = u32x4; };
+template <> struct vec_of<8> { using type = u32x2; };
+template <> struct vec_of<4> { using type = uint32_t; };
+template <> struct vec_of<2> { using type = uint16_t; };
+template <> struct vec_of<1> { using type = uint8_t; };
+
+constexpr int kGatherThreads = 256;
+constexpr int kGatherUnroll = 4;
+
+struct GatherGeom {
+  int vec;        // bytes per lane access (16/8/4/2/1)
+  int chunks;     // row_bytes / vec
+  int lpr_log2;   // lanes per row (log2)
+  int64_t grid;   // workgroups wanted
+};
+
+static inline GatherGeom gather_geometry(const void* src, const void* dst, int64_t row_bytes, int64_t n) {
+  GatherGeom g{};
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)row_bytes;
+  g.vec = 16;
+  while (g.vec > 1 && (a % g.vec) != 0) g.vec >>= 1;
+  g.chunks = (int)(row_bytes / g.vec);
+  g.lpr_log2 = 0;
+  while ((1 << g.lpr_log2) < g.chunks && g.lpr_log2 < 6) ++g.lpr_log2;
+  const int gpb = kGatherThreads >> g.lpr_log2;
+  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
+  g.grid = (n + rows_per_iter - 1) / rows_per_iter;
+  const int64_t max_grid = 256 * 16;  // 256 CUs x 16 workgroups: grid-stride beyond that
+  if (g.grid > max_grid) g.grid = max_grid;
+  if (g.grid < 1) g.grid = 1;
+  return g;
+}
+
+template <int VEC, typename IdxT>
+__device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
+                                                 int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
+                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+  using V = typename vec_of<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int g = threadIdx.x >> lpr_log2;
+  const int l = threadIdx.x & (lpr - 1);
+  const int gpb = kGatherThreads >> lpr_log2;  // row groups per workgroup
+  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
+  for (int64_t base = vblock * rows_per_iter; base < n; base += nvblocks * rows_per_iter) {
+    const V* s[kGatherUnroll];
+    V* d[kGatherUnroll];
+    bool ok[kGatherUnroll];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) {
+      const int64_t r = base + (int64_t)u * gpb + g;
+      ok[u] = r < n;
+      const int64_t sr = ok[u] ? (int64_t)idx[r] : 0;
+      s[u] = reinterpret_cast<const V*>(src + sr * row_bytes);
+      d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
+    }
+    for (int c = l; c < chunks; c += lpr) {
+      V v[kGatherUnroll];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u)
+        if (ok[u]) v[u] = __builtin_nontemporal_load(&s[u][c]);  // read-once rows: keep the node tables in MALL
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u)
+        if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);
+    }
+  }
+}
+
+}  // namespace spp

@@ -39,6 +39,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "gather_body.cuh"
 #include "mt19937.cuh"
 #include "sampler_internal.h"
 
@@ -447,13 +448,58 @@ struct ExportSegs {
   int64_t start[2 * SPP_MAX_HOPS + 2];
 };
 
-__global__ __launch_bounds__(kNT) void k_export(ExportSegs g) {
+__device__ __forceinline__ void export_body(const ExportSegs& g, int64_t vblock, int64_t nvblocks) {
   const int64_t total = g.start[g.n];
-  for (int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kNT) {
+  for (int64_t i = vblock * kNT + threadIdx.x; i < total; i += nvblocks * kNT) {
     int sgi = 0;
     while (sgi + 1 < g.n && i >= g.start[sgi + 1]) ++sgi;
     const int64_t k = i - g.start[sgi];
     g.dst[sgi][k] = (int64_t)g.src[sgi][k];
+  }
+}
+
+__global__ __launch_bounds__(kNT) void k_export(ExportSegs g) { export_body(g, blockIdx.x, gridDim.x); }
+
+// Fused delivery of one batch to the caller's tensors in ONE launch (the three separate launches
+// cost ~40 us of host-side gaps per batch): workgroups [0, nb_x) gather the feature rows
+// x[n_id[i],:], [nb_x, nb_x+nb_e) widen the MFG arrays to int64, the rest gather the label rows.
+struct DeliverArgs {
+  ExportSegs segs;
+  // x = x_src[n_id[:U], :]
+  const char* x_src;
+  char* x_dst;
+  int64_t x_rows, x_row_bytes;
+  int x_chunks, x_lpr_log2;
+  int32_t nb_x, nb_e, nb_y;
+  // y = y_src[n_id[:bs], :]
+  const char* y_src;
+  char* y_dst;
+  int64_t y_rows, y_row_bytes;
+  const int32_t* n_ids;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
+  static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
+  const int b = blockIdx.x;
+  if (b < a.nb_x) {
+    gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
+                                   a.nb_x);
+  } else if (b < a.nb_x + a.nb_e) {
+    export_body(a.segs, b - a.nb_x, a.nb_e);
+  } else {
+    // label rows are tiny (batch_size x 8 B): one lane per row, byte loop
+    const int64_t vb = b - a.nb_x - a.nb_e;
+    for (int64_t r = vb * kNT + threadIdx.x; r < a.y_rows; r += (int64_t)a.nb_y * kNT) {
+      const char* s = a.y_src + (int64_t)a.n_ids[r] * a.y_row_bytes;
+      char* d = a.y_dst + r * a.y_row_bytes;
+      if ((a.y_row_bytes & 7) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 7) == 0) {
+        for (int64_t k = 0; k < a.y_row_bytes; k += 8)
+          *reinterpret_cast<uint64_t*>(d + k) = *reinterpret_cast<const uint64_t*>(s + k);
+      } else {
+        for (int64_t k = 0; k < a.y_row_bytes; ++k) d[k] = s[k];
+      }
+    }
   }
 }
 
@@ -800,6 +846,77 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     sl.sampled = true;
     sl.waited = false;
   }
+  return SPP_OK;
+}
+
+// Fused delivery of the (waited) batch in `slot` on the caller's stream: MFG widening + x and y
+// row gathers in one launch.  Any of mfg / x / y may be absent.
+spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
+                           void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
+                           hipStream_t st) {
+  SlotHost& sl = s->slots[(size_t)slot];
+  if (!sl.sampled || !sl.waited) {
+    set_error("spp_session_export: slot %d must be sampled and waited first", slot);
+    return SPP_ERR_STATE;
+  }
+  const SlotState* hs = sl.host_state;
+  const int H = s->cfg.num_hops;
+  const int64_t U = hs->cnt[H];
+  DeliverArgs a{};
+  int n = 0;
+  int64_t total = 0;
+  auto add = [&](const int32_t* src, int64_t* dst, int64_t len) {
+    if (len <= 0 || dst == nullptr) return;
+    a.segs.src[n] = src;
+    a.segs.dst[n] = dst;
+    a.segs.start[n] = total;
+    total += len;
+    ++n;
+  };
+  if (mfg) {
+    add(sl.p.n_ids, mfg->n_id, U);
+    for (int k = 0; k < H; ++k) {
+      const int h = H - 1 - k;
+      add(sl.p.out_rowptr[h], mfg->rowptr[k], (int64_t)hs->cnt[h] + 1);
+      add(sl.p.out_col[h], mfg->col[k], hs->E[h]);
+    }
+  }
+  a.segs.n = n;
+  a.segs.start[n] = total;
+  a.n_ids = sl.p.n_ids;
+  a.nb_e = total > 0 ? (int32_t)std::min<int64_t>(ceil_div(total, kNT), 1024) : 0;
+  int vec = 1;
+  if (x_src && x_dst && U > 0 && x_row_bytes > 0) {
+    const GatherGeom gg = gather_geometry(x_src, x_dst, x_row_bytes, U);
+    vec = gg.vec;
+    a.x_src = static_cast<const char*>(x_src);
+    a.x_dst = static_cast<char*>(x_dst);
+    a.x_rows = U;
+    a.x_row_bytes = x_row_bytes;
+    a.x_chunks = gg.chunks;
+    a.x_lpr_log2 = gg.lpr_log2;
+    a.nb_x = (int32_t)gg.grid;
+  }
+  const int64_t ny = std::min<int64_t>(y_rows, U);
+  if (y_src && y_dst && ny > 0 && y_row_bytes > 0) {
+    a.y_src = static_cast<const char*>(y_src);
+    a.y_dst = static_cast<char*>(y_dst);
+    a.y_rows = ny;
+    a.y_row_bytes = y_row_bytes;
+    a.nb_y = (int32_t)std::min<int64_t>(ceil_div(ny, kNT), 64);
+  }
+  const unsigned grid = (unsigned)(a.nb_x + a.nb_e + a.nb_y);
+  if (grid == 0) return SPP_OK;
+  const int prof = prof_begin(SPP_PROF_GATHER, st, a.x_rows);
+  switch (vec) {
+    case 16: hipLaunchKernelGGL(k_deliver<16>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(k_deliver<8>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(k_deliver<4>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_deliver<2>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_deliver<1>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+  }
+  prof_end(SPP_PROF_GATHER, prof, st);
+  SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }
 

@@ -20,4 +20,10 @@ spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, co
 spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
                                 const int64_t* n_seeds, hipStream_t st);
 
+// Fused delivery of the waited batch in `slot` to caller buffers in one launch on `st`:
+// MFG widening (mfg may be NULL), x = x_src[n_id,:], y = y_src[n_id[:y_rows],:].
+spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
+                           void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
+                           hipStream_t st);
+
 }  // namespace spp

@@ -13,9 +13,9 @@
 //
 // Scheduling.  Consecutive batches are sampled in GROUPS of G (one launch sequence per group, see
 // sampler.hip); the `max_items_in_queue` slots form max_items/G slot-sets, each with its own HIP
-// stream.  The mt19937 streams of a group are generated one slot-set generation AHEAD on a separate
-// stream into the idle half of a per-slot ping-pong buffer, so the serial generator never delays a
-// sampling chain.  When the last batch of a group has been exported, its slot-set immediately
+// stream.  The mt19937 streams of a group are generated one slot-set generation AHEAD, at the tail
+// of the same stream, into the idle half of a per-slot ping-pong buffer, so the serial generator
+// never delays a sampling chain.  When the last batch of a group has been exported, its slot-set immediately
 // starts the next pending group (ordered after the consumer's copies by events).
 #include "spp_internal.h"
 
@@ -36,13 +36,8 @@ struct spp_session {
   int num_sets = 1;          // slot-sets in flight
   int64_t num_groups = 0;    // groups in this epoch
   std::vector<hipStream_t> streams;      // one per slot-set
-  hipStream_t rng_stream = nullptr;
-  std::vector<hipEvent_t> rng_done;      // [set*2 + buf]
-  std::vector<hipEvent_t> chain_done;    // [set*2 + buf]
-  std::vector<char> chain_recorded;      // [set*2 + buf]
   std::vector<hipEvent_t> export_done;   // per slot
   std::vector<char> export_recorded;     // per slot
-  int64_t rng_launched = 0;              // groups whose RNG streams were launched
   int64_t chain_launched = 0;            // groups whose sampling chain was launched
   int64_t next_to_deliver = 0;           // batch index
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
@@ -89,20 +84,20 @@ static inline int group_len(const spp_session* s, int64_t g) {
   return (int)std::min<int64_t>(s->G, nb - g * s->G);
 }
 
+// mt19937 streams of group g into its RNG buffer, enqueued on the group's own slot-set stream
 static spp_status launch_group_rng(spp_session* s, int64_t g) {
   const int set = (int)(g % s->num_sets);
   const int buf = (int)((g / s->num_sets) & 1);
   const int n = group_len(s, g);
   uint32_t seeds[kMaxGroup];
   for (int i = 0; i < n; ++i) seeds[i] = spp_batch_seed(s->ranges[(size_t)(g * s->G + i)].second);  // :994
-  // the previous user of this RNG buffer (group g - 2*num_sets) must have finished sampling
-  if (s->chain_recorded[(size_t)(set * 2 + buf)])
-    SPP_HIP_TRY(hipStreamWaitEvent(s->rng_stream, s->chain_done[(size_t)(set * 2 + buf)], 0));
-  SPP_TRY(sampler_launch_rng(s->sampler, set * s->G, n, buf, seeds, nullptr, s->rng_stream));
-  SPP_HIP_TRY(hipEventRecord(s->rng_done[(size_t)(set * 2 + buf)], s->rng_stream));
-  return SPP_OK;
+  return sampler_launch_rng(s->sampler, set * s->G, n, buf, seeds, nullptr, s->streams[(size_t)set]);
 }
 
+// Stream of a slot-set, in order:  [rng(g) only for the set's first group] wait(exports of the
+// previous group) -> chain(g) -> completion event -> rng(g + num_sets) into the other RNG buffer.
+// The generator therefore runs in the stream's idle time while the consumer drains other groups;
+// a separate RNG stream turned out to share a hardware queue with a chain and serialise behind it.
 static spp_status launch_group_chain(spp_session* s, int64_t g) {
   const int set = (int)(g % s->num_sets);
   const int buf = (int)((g / s->num_sets) & 1);
@@ -115,7 +110,7 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
     seeds[i] = s->cfg.idx_dev + r.first;
     n_seeds[i] = (int64_t)r.second - r.first;
   }
-  SPP_HIP_TRY(hipStreamWaitEvent(st, s->rng_done[(size_t)(set * 2 + buf)], 0));
+  if (g < s->num_sets) SPP_TRY(launch_group_rng(s, g));
   // the consumer's copies out of these slots (previous group of this slot-set) must be done
   for (int i = 0; i < s->G; ++i) {
     const size_t slot = (size_t)(set * s->G + i);
@@ -125,25 +120,15 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
     }
   }
   SPP_TRY(sampler_launch_chain(s->sampler, set * s->G, n, buf, seeds, n_seeds, st));
-  SPP_HIP_TRY(hipEventRecord(s->chain_done[(size_t)(set * 2 + buf)], st));
-  s->chain_recorded[(size_t)(set * 2 + buf)] = 1;
+  if (g + s->num_sets < s->num_groups) SPP_TRY(launch_group_rng(s, g + s->num_sets));
   return SPP_OK;
 }
 
-// keep the pipeline full: chains for up to num_sets groups beyond the ones fully consumed, RNG one
-// slot-set generation further
+// keep the pipeline full: chains for up to num_sets groups beyond the ones fully consumed
 static spp_status pump(spp_session* s, int64_t groups_fully_consumed) {
   while (s->chain_launched < s->num_groups && s->chain_launched < groups_fully_consumed + s->num_sets) {
-    if (s->rng_launched <= s->chain_launched) {
-      SPP_TRY(launch_group_rng(s, s->rng_launched));
-      s->rng_launched++;
-    }
     SPP_TRY(launch_group_chain(s, s->chain_launched));
     s->chain_launched++;
-  }
-  while (s->rng_launched < s->num_groups && s->rng_launched < s->chain_launched + s->num_sets) {
-    SPP_TRY(launch_group_rng(s, s->rng_launched));
-    s->rng_launched++;
   }
   return SPP_OK;
 }
@@ -224,12 +209,6 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   };
   s->streams.assign((size_t)sets, nullptr);
   for (auto& st : s->streams) mk_stream(&st);
-  mk_stream(&s->rng_stream);
-  s->rng_done.assign((size_t)sets * 2, nullptr);
-  s->chain_done.assign((size_t)sets * 2, nullptr);
-  s->chain_recorded.assign((size_t)sets * 2, 0);
-  for (auto& e : s->rng_done) mk_event(&e);
-  for (auto& e : s->chain_done) mk_event(&e);
   s->export_done.assign((size_t)(sets * G), nullptr);
   s->export_recorded.assign((size_t)(sets * G), 0);
   for (auto& e : s->export_done) mk_event(&e);
@@ -247,17 +226,11 @@ extern "C" void spp_session_destroy(spp_session* s) {
   (void)hipSetDevice(s->cfg.device);
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
-  if (s->rng_stream) (void)hipStreamSynchronize(s->rng_stream);
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
-  for (auto ev : s->rng_done)
-    if (ev) (void)hipEventDestroy(ev);
-  for (auto ev : s->chain_done)
-    if (ev) (void)hipEventDestroy(ev);
   for (auto ev : s->export_done)
     if (ev) (void)hipEventDestroy(ev);
   for (auto st : s->streams)
     if (st) (void)hipStreamDestroy(st);
-  if (s->rng_stream) (void)hipStreamDestroy(s->rng_stream);
   delete s;
 }
 
@@ -328,11 +301,12 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   const int32_t slot = s->current_slot;
   const int64_t b = s->next_to_deliver - 1;
   const int64_t bs = (int64_t)s->ranges[(size_t)b].second - s->ranges[(size_t)b].first;
-  if (mfg) SPP_TRY(spp_sampler_export(s->sampler, slot, mfg, stream));
-  if (x_src_dev && x_out_dev)  // x_s = serial_index(x, n_id)            (fast_sampler.cpp:1006)
-    SPP_TRY(spp_sampler_gather(s->sampler, slot, x_src_dev, x_rows, x_row_bytes, -1, x_out_dev, stream));
-  if (y_src_dev && y_out_dev)  // y_s = serial_index(y, n_id, batch_size) (fast_sampler.cpp:1009)
-    SPP_TRY(spp_sampler_gather(s->sampler, slot, y_src_dev, y_rows, y_row_bytes, bs, y_out_dev, stream));
+  (void)x_rows;
+  (void)y_rows;
+  // one launch: MFG widening, x_s = serial_index(x, n_id) (fast_sampler.cpp:1006) and
+  // y_s = serial_index(y, n_id, batch_size) (fast_sampler.cpp:1009)
+  SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
+                          y_out_dev, as_stream(stream)));
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
   s->export_recorded[(size_t)slot] = 1;
   return retire_current(s);

@@ -371,6 +371,12 @@ class Session:
             raise
         self._h = h
         self._desc = nat.BatchDesc()
+        self._e_id = torch.empty(0, dtype=torch.int64, device=self._dev)
+        # (src pointer, rows, row bytes) of the resident feature / label matrices, built once
+        self._x_args = (C.c_void_p(self._x.data_ptr()), self._x.size(0), self._x.size(1) * self._x.element_size()) \
+            if self._x is not None and self._x.numel() else (None, 0, 0)
+        self._y_args = (C.c_void_p(self._y.data_ptr()), self._y.size(0), self._y.size(1) * self._y.element_size()) \
+            if self._y is not None and self._y.numel() else (None, 0, 0)
         self._part_ws = None
         self._slice_result = []
         # remote-frequency statistics (count_remote_frequency, fast_sampler.cpp:1093-1103 / :835-880)
@@ -422,20 +428,31 @@ class Session:
         return rc == 1
 
     def _alloc_mfg(self, counts, want_n_id=True):
-        dev = self._dev
+        """One int64 arena per batch for n_id and every hop's rowptr/col (a single allocator call
+        instead of 2*hops+1), handed out as views; `e_id` is the shared empty tensor."""
+        H = counts.num_hops
+        U = int(counts.num_nodes) if want_n_id else 0
+        Ts = [int(counts.T[k]) for k in range(H)]
+        Es = [int(counts.E[k]) for k in range(H)]
+        arena = torch.empty(U + sum(Ts) + H + sum(Es), dtype=torch.int64, device=self._dev)
+        base = arena.data_ptr()
         out = nat.MfgOut()
         n_id = None
+        off = 0
         if want_n_id:
-            n_id = torch.empty(counts.num_nodes, dtype=torch.int64, device=dev)
-            out.n_id = n_id.data_ptr() if n_id.numel() else None
+            n_id = arena[:U]
+            out.n_id = base if U else None
+            off = U
         adjs = []
-        e_id = torch.empty(0, dtype=torch.int64, device=dev)          # sample_cpu.hpp:120: always empty
-        for k in range(counts.num_hops):
-            rp = torch.empty(counts.T[k] + 1, dtype=torch.int64, device=dev)
-            cl = torch.empty(counts.E[k], dtype=torch.int64, device=dev)
-            out.rowptr[k] = rp.data_ptr()
-            out.col[k] = cl.data_ptr() if cl.numel() else None
-            adjs.append((rp, cl, e_id, (int(counts.T[k]), int(counts.S[k]))))
+        e_id = self._e_id                                              # sample_cpu.hpp:120: always empty
+        for k in range(H):
+            rp = arena[off:off + Ts[k] + 1]
+            out.rowptr[k] = base + 8 * off
+            off += Ts[k] + 1
+            cl = arena[off:off + Es[k]]
+            out.col[k] = (base + 8 * off) if Es[k] else None
+            off += Es[k]
+            adjs.append((rp, cl, e_id, (Ts[k], int(counts.S[k]))))
         return out, n_id, adjs
 
     def blocking_get_batch(self):
@@ -459,14 +476,13 @@ class Session:
     try_get_batch = blocking_get_batch
 
     def _export(self, out, x, y):
-        xs, ys = self._x, self._y
+        xa = self._x_args if x is not None and self._x is not None else (None, 0, 0)
+        ya = self._y_args if y is not None and self._y is not None else (None, 0, 0)
         nat.check(self._L.spp_session_export(
             self._h, C.byref(out),
-            _ptr(xs) if x is not None and xs is not None else None, xs.size(0) if xs is not None else 0,
-            xs.size(1) * xs.element_size() if xs is not None else 0, _ptr(x) if xs is not None else None,
-            _ptr(ys) if y is not None and ys is not None else None, ys.size(0) if ys is not None else 0,
-            ys.size(1) * ys.element_size() if ys is not None else 0, _ptr(y) if ys is not None else None,
-            _stream_ptr()))
+            xa[0], xa[1], xa[2], C.c_void_p(x.data_ptr()) if xa[0] is not None and x.numel() else None,
+            ya[0], ya[1], ya[2], C.c_void_p(y.data_ptr()) if ya[0] is not None and y.numel() else None,
+            C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)))
 
     def blocking_get_batch_distributed(self):
         """-> None or ProtoDistributedBatch (worker distributed branch, fast_sampler.cpp:1017-1272)."""

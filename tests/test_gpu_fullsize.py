@@ -1,0 +1,102 @@
+"""-m gpu: parity at BASELINE.json's full single-GPU size (S-products scale: 2.45 M nodes,
+123.7 M edges, F=100, batch 1024, fanout [15,10,5]).  Two whole batches are compared bit-for-bit
+with the oracle (≈0.5 s of CPU each); every batch of a longer run is checked through
+size-independent properties of the MFG."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def products():
+    from salient_plusplus_amd import _native as nat
+    nat.load()
+    nat.require_device()
+    from salient_plusplus_amd.synthetic import make_workload
+    wl = make_workload("S-products", seed=1234, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    return wl
+
+
+def _sampler(wl, idx, slots=24):
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+    bs = wl.batch_size
+    cfg = FastSamplerConfig(
+        x_cpu=wl.x, x_gpu=torch.empty(0), y=wl.y.unsqueeze(-1), rowptr=wl.rowptr, col=wl.col, idx=idx,
+        batch_size=bs, sizes=wl.fanouts, skip_nonfull_batch=False, pin_memory=False, distributed=False,
+        partition_book=None, cache=fs.Cache(), force_exact_num_batches=True,
+        exact_num_batches=max(1, idx.numel() // bs), count_remote_frequency=False, use_cache=False)
+    return FastSampler(4, slots, cfg)
+
+
+def test_fullsize_batches_bit_exact_vs_oracle(products):
+    from oracle import oracle as orc
+    wl = products
+    idx = wl.train_idx[:20 * wl.batch_size].contiguous()          # 20 batches -> several groups in flight
+    rowptr, col, idx_h = wl.rowptr.cpu().numpy(), wl.col.cpu().numpy(), idx.cpu().numpy()
+    x_h, y_h = wl.x.cpu().numpy(), wl.y.cpu().numpy()
+    ranges = orc.batch_ranges(idx.numel(), wl.batch_size, False, True, 20)
+    check = {0, 13}                                              # first group, and a batch of a later group
+    for b, batch in enumerate(iter(_sampler(wl, idx))):
+        start, stop = int(ranges[b][0]), int(ranges[b][1])
+        assert (batch.idx_range.start, batch.idx_range.stop) == (start, stop)
+        if b not in check:
+            continue
+        m = orc.sample_batch(rowptr, col, idx_h, start, stop, wl.fanouts)
+        assert m.num_edges > 900_000
+        for adj, hop in zip(batch.adjs, m.hops):
+            rp, cl, _ = adj.adj_t.csr()
+            np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
+            np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+            assert tuple(adj.size) == tuple(hop.size[::-1])
+        np.testing.assert_array_equal(batch.x.cpu().numpy().view(np.uint16), x_h[m.n_id].view(np.uint16))
+        np.testing.assert_array_equal(batch.y.cpu().numpy(), y_h[m.n_id[:stop - start]])
+
+
+def test_fullsize_epoch_properties(products):
+    """Size-independent invariants on every batch of a 48-batch run."""
+    from salient_plusplus_amd import fast_sampler as fs
+    wl = products
+    nb = 48
+    idx = wl.train_idx[:nb * wl.batch_size].contiguous()
+    deg = (wl.rowptr[1:] - wl.rowptr[:-1])
+    fan = wl.fanouts
+    seen = 0
+    s = fs.Session(4, 24, _sampler(wl, idx).cfg.to_fast_sampler())
+    try:
+        while True:
+            b = s.blocking_get_batch_distributed() if False else s.blocking_get_batch()
+            if b is None:
+                break
+            x, y, adjs, (start, stop) = b
+            U = x.size(0)
+            assert stop - start == wl.batch_size and y.shape == (wl.batch_size, 1)
+            # hops are outermost first; target nodes are a prefix of the source nodes
+            T_prev = None
+            for k, (rp, cl, e_id, (T, S)) in enumerate(adjs):
+                f = fan[len(fan) - 1 - k]
+                assert e_id.numel() == 0 and rp.numel() == T + 1 and S >= T
+                if k == 0:
+                    assert S == U
+                if T_prev is not None:
+                    assert S == T_prev
+                T_prev = T
+                cnt = rp[1:] - rp[:-1]
+                assert int(rp[0]) == 0 and int(rp[-1]) == cl.numel() and bool((cnt >= 0).all())
+                assert int(cnt.max()) <= f
+                assert bool(((cl >= 0) & (cl < S)).all())
+                # rows sorted by local id: within a row col is non-decreasing
+                if cl.numel() > 1:
+                    row_of = torch.repeat_interleave(torch.arange(T, device=cl.device), cnt)
+                    same = row_of[1:] == row_of[:-1]
+                    assert bool((cl[1:][same] >= cl[:-1][same]).all())
+            assert adjs[-1][3][0] == wl.batch_size
+            seen += 1
+    finally:
+        s.close()
+    assert seen == nb
+    del deg
