@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "24")))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-model-step", action="store_true",
+                    help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
@@ -53,6 +55,69 @@ def host_cpu_share() -> int:
     except (OSError, ValueError):
         pass
     return n
+
+
+class TorchSAGE(torch.nn.Module):
+    """Consumer stand-in for the epoch-time figure: the reference's SAGE (driver/models.py:19-56:
+    3 x SAGEConv(bias=False, mean aggregation) + ReLU + dropout 0.5 + log_softmax) written with
+    plain torch ops on the MFG's CSR, because PyG / torch_sparse are not installed in this image.
+    It is NOT part of the product (the model step stays PyG in SALIENT++) and is never in `value`."""
+
+    def __init__(self, in_c, hid, out_c, num_layers=3):
+        super().__init__()
+        dims = [in_c] + [hid] * (num_layers - 1) + [out_c]
+        self.lin_l = torch.nn.ModuleList(torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers))
+        self.lin_r = torch.nn.ModuleList(torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers))
+        self.num_layers = num_layers
+
+    @staticmethod
+    def mean_aggregate(x, rowptr, col, n_dst):
+        cnt = rowptr[1:] - rowptr[:-1]
+        row = torch.repeat_interleave(torch.arange(n_dst, device=x.device), cnt)
+        out = torch.zeros((n_dst, x.size(1)), dtype=x.dtype, device=x.device).index_add_(0, row, x[col])
+        return out / cnt.clamp(min=1).unsqueeze(-1).to(x.dtype)
+
+    def forward(self, x, adjs):
+        x = x.to(torch.float)
+        for i, (adj_t, _e_id, size) in enumerate(adjs):
+            rowptr, col, _ = adj_t.csr()
+            x_target = x[:size[1]]
+            x = self.lin_l[i](self.mean_aggregate(x, rowptr, col, size[1])) + self.lin_r[i](x_target)
+            if i != self.num_layers - 1:
+                x = torch.nn.functional.dropout(torch.relu(x), p=0.5, training=self.training)
+        return torch.log_softmax(x, dim=-1)
+
+
+def model_step_timing(feeder, F, n_classes, steps=24, warm=4):
+    """ms/step of fwd+bwd+Adam with the data path feeding it, and with one resident batch re-used."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model = TorchSAGE(F, 256, n_classes).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def step(b):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.nll_loss(model(b.x, b.adjs), b.y.reshape(-1))
+        loss.backward()
+        opt.step()
+
+    fixed = feeder.next()
+    for _ in range(warm):
+        step(fixed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(fixed)
+    torch.cuda.synchronize()
+    model_only = (time.perf_counter() - t0) / steps
+    for _ in range(warm):
+        step(feeder.next())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(feeder.next())
+    torch.cuda.synchronize()
+    with_data = (time.perf_counter() - t0) / steps
+    return model_only * 1e3, with_data * 1e3
 
 
 def count_edges(batch) -> int:
@@ -127,12 +192,16 @@ def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
             kind, run = "reference", run_reference
         except Exception as e:  # noqa: BLE001
             print(f"[bench] reference module unusable here ({e}); timing the oracle port", file=sys.stderr)
-    probe_batches = max(2, threads)
+    probe_batches = max(2, 2 * threads)
     e, nb, dt = run(probe_batches)
     per_batch = dt / max(nb, 1)
-    n = int(max(probe_batches, min(idx.numel() // batch_size, seconds / max(per_batch, 1e-6))))
-    if n > nb:
-        e, nb, dt = run(n)
+    avail = max(1, idx.numel() // batch_size)
+    want = max(probe_batches, int(seconds / max(per_batch, 1e-6)))
+    e = nb = 0
+    dt = 0.0
+    while nb < want:                      # whole passes over the epoch's seeds until ~`seconds` of CPU work
+        e1, nb1, dt1 = run(min(avail, want - nb))
+        e, nb, dt = e + e1, nb + nb1, dt + dt1
     return {"value": e / dt, "unit": "sampled-edges/s", "cores": threads, "kind": kind,
             "sample": f"{nb} batches of {batch_size} seeds ({e} sampled edges) in {dt:.2f}s, "
                       f"{threads} worker threads, incl. feature/label slicing",
@@ -258,13 +327,14 @@ def main():
         # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
         row_bytes = F * 2
         alg_bytes_per_row = 2 * row_bytes + 8          # read row + write row + int64 index
-        # N == 1: every step launches the x gather and the (tiny) label gather; the label rows are
-        # taken out of the row count, their ~2 us launches stay in the time (conservative).
-        x_rows = rows.value if distributed else rows.value - a.steps * bs
+        # One profiled launch per batch.  N == 1: the fused delivery kernel (x-row gather + the small
+        # label gather and int64 widening of the MFG, which are charged to the gather's time but not
+        # to its bytes: conservative).  N > 1: the fused assembly kernel.
+        x_rows = rows.value
         x_ms = ms.value
-        launches_x = n_launch.value if distributed else n_launch.value // 2
+        launches_x = n_launch.value
         achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_assemble" if distributed else "k_gather_rows",
+        roof = {"bound": "hbm", "kernel": "k_assemble" if distributed else "k_deliver (gather_rows_body)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
@@ -292,6 +362,16 @@ def main():
             "graph_build_s": t_build,
             "roofline": roof,
         }
+        if not a.no_model_step and not distributed:
+            try:
+                m_only, m_data = model_step_timing(feeder, F, 47)
+                nb_epoch = wl.train_idx.numel() // bs
+                out["epoch_time_s_with_sage_step"] = nb_epoch * m_data / 1e3
+                out["model_step"] = {"model": "SAGE 3x256 (plain-torch stand-in, fp32, Adam)",
+                                     "ms_per_step_model_only_resident_batch": m_only,
+                                     "ms_per_step_with_data_path": m_data}
+            except Exception as e:  # noqa: BLE001
+                out["model_step"] = {"error": repr(e)}
         if not a.no_cpu_baseline and not distributed:
             threads = host_cpu_share()
             host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
