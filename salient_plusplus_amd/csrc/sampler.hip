@@ -52,7 +52,18 @@ constexpr int kNT = 256;         // workgroup size of the per-target / per-edge 
 constexpr int kFastMaxFanout = 32;
 constexpr int kScanNT = 1024;
 
-enum : int32_t { kErrEdgeCap = 1, kErrNodeCap = 2, kErrDrawCap = 4 };
+enum : int32_t { kErrEdgeCap = 1, kErrNodeCap = 2, kErrDrawCap = 4, kErrBucketCap = 8 };
+
+// Geometry of the radix-partitioned dedup (fixed per sampler).
+struct DedupGeom {
+  int32_t nb_log2;   // log2(#buckets), buckets = top bits of hash_node(key)
+  int32_t nb;        // #buckets (<= kMaxBuckets)
+  int32_t kcap;      // capacity of one bucket's known-node list
+};
+constexpr int kMaxBucketsLog2 = 12;
+constexpr int kMaxBuckets = 1 << kMaxBucketsLog2;
+constexpr int kBucketTile = 4096;           // edges one workgroup partitions per pass
+constexpr uint32_t kPending = 0x80000000u;  // known-list value = kPending | edge position of the previous hop
 
 // device-resident bookkeeping of one batch slot (copied to pinned host memory after sampling)
 struct SlotState {
@@ -69,11 +80,14 @@ struct SlotPtrs {
   int32_t* deg;
   int64_t* rowstart;
   int32_t* cval;       // neighbour node id of every edge position (later: local id, generic path)
-  uint32_t* eslot;     // node-table slot of every edge position
-  uint32_t* evals;     // node-table value seen by every edge position
+  unsigned long long* bpairs;  // edges regrouped by bucket: (node id << 32) | edge position
+  uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
   int32_t* erank;      // exclusive rank among first occurrences (also Floyd scratch, generic path)
-  unsigned long long* table;
-  uint32_t tab_mask;
+  unsigned long long* known;   // [nb][kcap] known nodes per bucket: (node id << 32) | local id (or kPending | pos)
+  int32_t* kcount;     // [nb] entries in each known list
+  int32_t* bcount;     // [nb] edges per bucket of the current hop (zero between hops)
+  int32_t* boff;       // [nb+1] exclusive offsets of the buckets in bpairs
+  int32_t* bcur;       // [nb] scatter cursors
   uint32_t* rng[2];    // draws rng_skip .. of the batch stream (ping-pong: generated one group ahead)
   int32_t* bsum0;
   int32_t* bsum1;
@@ -94,35 +108,58 @@ struct GroupArgs {
 };
 
 // ----------------------------------------------------------------------------------------------
-// node table
+// node table: radix-partitioned, LDS resident
 // ----------------------------------------------------------------------------------------------
-// Insert-or-update with min (kMax = false) / max (kMax = true) on the value.  The plain probe load
-// may be stale, but a slot only ever moves EMPTY -> key and its value only moves in the update
-// direction, so a stale value can only cause a redundant atomic, never a missed one.  Nodes that
-// are already final (value < T) and repeated neighbours therefore cost no atomic at all -- global
-// atomics to scattered lines run at a fraction of the HBM rate (MI355X_MICROARCH, float atomics).
+// A global hash table costs one random 64/128-B fabric transaction per probe, per atomic and per
+// re-read for 8 useful bytes (measured: ~540 MB of L2<->fabric traffic per batch for ~21 MB of
+// algorithmic bytes).  Instead the edges of a hop are regrouped by BUCKET (top bits of the node-id
+// hash) with sequential traffic, and one workgroup per bucket resolves its keys in an LDS table that
+// also holds the bucket's already-known nodes; only the per-edge result goes back to HBM.
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, int32_t nb_log2) {
+  return nb_log2 ? (hash_node(key) >> (32 - nb_log2)) : 0u;
+}
+
+__device__ __forceinline__ uint32_t lds_slot_of(uint32_t key, int lds_log2) {
+  return (key * 0x85EBCA6Bu) >> (32 - lds_log2);  // second multiplicative hash: independent of the bucket bits
+}
+
+// Insert-or-update with min (kMax = false) / max (kMax = true) on the value; *ovf is set when the
+// table is full.  LDS atomics of one workgroup are coherent, the pre-read only saves atomics.
 template <bool kMax>
-__device__ __forceinline__ uint32_t table_upsert(unsigned long long* table, uint32_t mask, uint32_t key,
-                                                 uint32_t val) {
+__device__ __forceinline__ void lds_upsert(unsigned long long* tab, uint32_t mask, int lds_log2, uint32_t key,
+                                           uint32_t val, int* ovf) {
   const unsigned long long entry = ((unsigned long long)key << 32) | val;
-  uint32_t h = hash_node(key) & mask;
-  for (;;) {
-    unsigned long long cur = table[h];
+  uint32_t h = lds_slot_of(key, lds_log2);
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    unsigned long long cur = tab[h];
     if (cur == kEmptySlot) {
-      cur = atomicCAS(&table[h], kEmptySlot, entry);
-      if (cur == kEmptySlot) return h;
+      cur = atomicCAS(&tab[h], kEmptySlot, entry);
+      if (cur == kEmptySlot) return;
     }
     if ((uint32_t)(cur >> 32) == key) {
       const uint32_t have = (uint32_t)cur;
       if (kMax) {
-        if (have < val) atomicMax(&table[h], entry);
+        if (have < val) atomicMax(&tab[h], entry);
       } else {
-        if (have > val) atomicMin(&table[h], entry);
+        if (have > val) atomicMin(&tab[h], entry);
       }
-      return h;
+      return;
     }
     h = (h + 1) & mask;
   }
+  *ovf = 1;
+}
+
+__device__ __forceinline__ uint32_t lds_find(const unsigned long long* tab, uint32_t mask, int lds_log2,
+                                             uint32_t key) {
+  uint32_t h = lds_slot_of(key, lds_log2);
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
+    const unsigned long long cur = tab[h];
+    if ((uint32_t)(cur >> 32) == key && cur != kEmptySlot) return (uint32_t)cur;
+    if (cur == kEmptySlot) break;
+    h = (h + 1) & mask;
+  }
+  return 0xffffffffu;
 }
 
 // the batch's mt19937 stream: draws [skip, skip + dcap) of mt19937(seed) -> rng[buf]
@@ -139,8 +176,9 @@ __global__ __launch_bounds__(kMtThreads) void k_rng_fill(const SlotPtrs* __restr
 }
 
 // get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
-// seed keeps its LAST position -> max.
-__global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga) {
+// seed keeps its LAST position: every seed is appended to its bucket's known list and the LDS
+// insert of known entries takes the max.
+__global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g) {
   const SlotPtrs& s = slots[ga.first_slot + blockIdx.y];
   const int64_t* __restrict__ seeds = ga.seeds[blockIdx.y];
   const int32_t n_seeds = ga.n_seeds[blockIdx.y];
@@ -153,7 +191,10 @@ __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ 
   if (i < n_seeds) {
     const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
     s.n_ids[i] = v;
-    table_upsert<true>(s.table, s.tab_mask, (uint32_t)v, (uint32_t)i);
+    const uint32_t b = bucket_of((uint32_t)v, g.nb_log2);
+    const int32_t j = atomicAdd(&s.kcount[b], 1);
+    if (j < g.kcap) s.known[(int64_t)b * g.kcap + j] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)i;
+    else atomicOr(&s.st->error, kErrBucketCap);
   }
 }
 
@@ -258,9 +299,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   const uint32_t* rng = s.rng[rng_buf];
   if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
   if (kGeneric) {
-    // only the Floyd picks are produced here (into erank[p0..p0+f)); expansion is edge-parallel
+    // only the Floyd picks are produced here (into evals[p0..p0+f), free at this point; erank still
+    // holds the previous hop's ranks, needed by k_bucket_dedup); expansion is edge-parallel
     if (smp) {
-      int32_t* mine = s.erank + p0;
+      int32_t* mine = reinterpret_cast<int32_t*>(s.evals) + p0;
       for (int32_t k = 0; k < f; ++k) {
         if (replace) {
           mine[k] = (int32_t)(rng[k] % (uint32_t)deg);
@@ -276,7 +318,6 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     return;
   }
   const int64_t rs = s.rowstart[i];
-  const uint32_t T_u = (uint32_t)T;
   const int tid = threadIdx.x;
   if (smp) {
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
@@ -293,18 +334,12 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       chosen[k][tid] = found ? j : option;
     }
   }
-  // all neighbour reads of the row are issued back to back (independent HBM misses) ...
+  // all neighbour reads of the row are issued back to back (independent HBM misses)
   for (int32_t k = 0; k < cnt; ++k) {
     const int32_t w = smp ? chosen[k][tid] : k;
     chosen[k][tid] = (int32_t)col[rs + w];
   }
-  // ... before the (serialising) table updates
-  for (int32_t k = 0; k < cnt; ++k) {
-    const int32_t c = chosen[k][tid];
-    const int32_t p = p0 + k;
-    s.cval[p] = c;
-    s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, T_u + (uint32_t)p);
-  }
+  for (int32_t k = 0; k < cnt; ++k) s.cval[p0 + k] = chosen[k][tid];
 }
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
@@ -327,10 +362,153 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
   const int32_t k = (int32_t)p - rp[i];
   int32_t cnt_, smp_;
   target_counts(deg, f, replace, cnt_, smp_);
-  const int32_t w = smp_ ? s.erank[p] : k;
-  const int32_t c = (int32_t)col[s.rowstart[i] + w];
-  s.cval[p] = c;
-  s.eslot[p] = table_upsert<false>(s.table, s.tab_mask, (uint32_t)c, (uint32_t)T + (uint32_t)p);
+  const int32_t w = smp_ ? (int32_t)s.evals[p] : k;
+  s.cval[p] = (int32_t)col[s.rowstart[i] + w];
+}
+
+// ----------------------------------------------------------------------------------------------
+// dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
+                                                      DedupGeom g) {
+  __shared__ int32_t lh[kMaxBuckets];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t E = s.st->E[h];
+  const int64_t base = (int64_t)blockIdx.x * kBucketTile;
+  if (base >= E || s.st->error) return;
+  for (int b = threadIdx.x; b < g.nb; b += kNT) lh[b] = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+    const int64_t p = base + k;
+    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < g.nb; b += kNT)
+    if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);
+}
+
+// exclusive scan of the bucket counts -> offsets and scatter cursors; the counts are re-zeroed
+__global__ __launch_bounds__(kScanNT) void k_bucket_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                          DedupGeom g) {
+  __shared__ int32_t lds[kScanNT / kWave + 1];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  int32_t carry = 0;
+  for (int32_t base = 0; base < g.nb; base += kScanNT) {
+    const int32_t b = base + threadIdx.x;
+    const int32_t v = (b < g.nb) ? s.bcount[b] : 0;
+    int32_t tot;
+    const int32_t ex = block_exclusive_scan<int32_t, kScanNT>(v, lds, &tot);
+    if (b < g.nb) {
+      s.boff[b] = carry + ex;
+      s.bcur[b] = carry + ex;
+      s.bcount[b] = 0;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s.boff[g.nb] = carry;
+}
+
+__global__ __launch_bounds__(kNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                         int32_t h, DedupGeom g) {
+  __shared__ int32_t lh[kMaxBuckets];    // tile histogram, then running cursor inside the reservation
+  __shared__ int32_t lbase[kMaxBuckets]; // start of this tile's reservation in each bucket
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t E = s.st->E[h];
+  const int64_t base = (int64_t)blockIdx.x * kBucketTile;
+  if (base >= E || s.st->error) return;
+  for (int b = threadIdx.x; b < g.nb; b += kNT) lh[b] = 0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+    const int64_t p = base + k;
+    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < g.nb; b += kNT) {
+    const int32_t c = lh[b];
+    lbase[b] = c ? atomicAdd(&s.bcur[b], c) : 0;
+    lh[b] = 0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+    const int64_t p = base + k;
+    if (p < E) {
+      const uint32_t c = (uint32_t)s.cval[p];
+      const uint32_t b = bucket_of(c, g.nb_log2);
+      const int32_t j = atomicAdd(&lh[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
+      s.bpairs[lbase[b] + j] = ((unsigned long long)c << 32) | (uint32_t)p;
+    }
+  }
+}
+
+// One workgroup per bucket: known nodes (ids from earlier hops; pending ones of the previous hop are
+// resolved through its rank array first) and this hop's candidates meet in an LDS table.
+//   value < T          : final local id of an already known node
+//   value = T + p      : p is the earliest edge position of this hop reaching the node
+// Every edge gets the final value of its node (evals[p]); the earliest edge of every new node appends
+// (node, kPending | p) to the bucket's known list for the later hops.
+template <int LDS_LOG2>
+__global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                       int32_t h, DedupGeom g) {
+  __shared__ unsigned long long tab[1 << LDS_LOG2];
+  __shared__ int n_new, ovf;
+  constexpr uint32_t mask = (1u << LDS_LOG2) - 1;
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  if (s.st->error) return;
+  const int32_t b = blockIdx.x;
+  const uint32_t T = (uint32_t)s.st->cnt[h];
+  const uint32_t Tprev = h > 0 ? (uint32_t)s.st->cnt[h - 1] : 0u;
+  unsigned long long* kl = s.known + (int64_t)b * g.kcap;
+  const int32_t kc = s.kcount[b];
+  const int32_t e0 = s.boff[b], e1 = s.boff[b + 1];
+  const bool work = e1 > e0;  // block-uniform
+  if (work) {
+    for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
+    if (threadIdx.x == 0) {
+      n_new = 0;
+      ovf = 0;
+    }
+    __syncthreads();
+  }
+  // known nodes: resolve the previous hop's pending ids (its rank array is overwritten by this hop's
+  // k_hop_assign, so this must happen now for EVERY bucket), then publish them in the LDS table
+  for (int i = threadIdx.x; i < kc; i += kNT) {
+    unsigned long long e = kl[i];
+    uint32_t val = (uint32_t)e;
+    if (val & kPending) {
+      val = Tprev + (uint32_t)s.erank[val & ~kPending];
+      e = (e & 0xffffffff00000000ull) | val;
+      kl[i] = e;
+    }
+    if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e >> 32), val, &ovf);
+  }
+  if (!work) return;
+  __syncthreads();
+  for (int i = e0 + threadIdx.x; i < e1; i += kNT) {
+    const unsigned long long pr = s.bpairs[i];
+    lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr >> 32), T + (uint32_t)pr, &ovf);
+  }
+  __syncthreads();
+  if (ovf) {
+    if (threadIdx.x == 0) atomicOr(&s.st->error, kErrBucketCap);
+    return;
+  }
+  for (int i = e0 + threadIdx.x; i < e1; i += kNT) {
+    const unsigned long long pr = s.bpairs[i];
+    const uint32_t key = (uint32_t)(pr >> 32), p = (uint32_t)pr;
+    const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
+    s.evals[p] = val;
+    if (val == T + p) {  // first occurrence of a new node
+      const int j = atomicAdd(&n_new, 1);
+      if (kc + j < g.kcap) kl[kc + j] = ((unsigned long long)key << 32) | kPending | p;
+      else ovf = 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ovf) atomicOr(&s.st->error, kErrBucketCap);
+    s.kcount[b] = kc + (n_new < g.kcap - kc ? n_new : g.kcap - kc);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -344,11 +522,7 @@ __global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ s
   const uint32_t T = (uint32_t)s.st->cnt[h];
   const int32_t p = blockIdx.x * kNT + threadIdx.x;
   int32_t flag = 0;
-  if (p < E) {
-    const uint32_t v = (uint32_t)(s.table[s.eslot[p]] & 0xffffffffu);
-    s.evals[p] = v;
-    flag = (v == T + (uint32_t)p) ? 1 : 0;
-  }
+  if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
   int32_t tot;
   block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
   if (threadIdx.x == 0) s.bsum0[blockIdx.x] = tot;
@@ -394,8 +568,7 @@ __global__ __launch_bounds__(kNT) void k_hop_assign(const SlotPtrs* __restrict__
     if (flag) {
       const int32_t c = s.cval[p];
       const uint32_t id = T + (uint32_t)r;
-      s.n_ids[id] = c;                                                    // n_ids.push_back(c)
-      s.table[s.eslot[p]] = ((unsigned long long)(uint32_t)c << 32) | id;  // final local id
+      s.n_ids[id] = c;  // n_ids.push_back(c); the known lists resolve this id lazily (kPending)
     }
   }
 }
@@ -530,14 +703,15 @@ struct spp_sampler {
   int64_t dcap = 0;
   bool generic[SPP_MAX_HOPS];
   bool any_generic = false;
-  uint32_t tab_size = 0;
+  DedupGeom geom{};
+  int lds_log2 = 13;                // LDS table slots of k_bucket_dedup (13: 64 KB, 14: 128 KB)
   int64_t bytes = 0;
   std::vector<SlotHost> slots;
   std::vector<void*> allocs;
   SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
-  unsigned long long* tables = nullptr;  // contiguous node tables (slot-major)
+  int32_t* counts = nullptr;         // [slot][2*nb]: kcount then bcount (zeroed per batch with one memset)
 };
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -593,9 +767,15 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     delete s;
     return SPP_ERR_INVALID;
   }
-  uint32_t tab = 1024;
-  while ((int64_t)tab < 2 * ucap) tab <<= 1;
-  s->tab_size = tab;
+  // dedup geometry: ~3k distinct nodes per bucket at the worst case, LDS table of 8k (or 16k) slots
+  int nb_log2 = 0;
+  while (nb_log2 < kMaxBucketsLog2 && (ucap >> nb_log2) > 3072) ++nb_log2;
+  s->geom.nb_log2 = nb_log2;
+  s->geom.nb = 1 << nb_log2;
+  const int64_t per_bucket = (ucap + s->geom.nb - 1) / s->geom.nb;
+  s->geom.kcap = (int32_t)std::min<int64_t>(per_bucket + per_bucket / 2 + 256, 0x7fffffff);
+  s->lds_log2 = per_bucket > 4096 ? 14 : 13;
+  const int nb = s->geom.nb;
   int64_t tmax = 0;
   for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
   const int64_t nblk_max = std::max(ceil_div(tmax, kNT), ceil_div(etmp, kNT)) + 1;
@@ -611,8 +791,12 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     s->d_states = static_cast<SlotState*>(v);
   }
   if (rc == SPP_OK) {
-    rc = dev_alloc(s, &v, sizeof(unsigned long long) * (size_t)tab * (size_t)nslots);
-    s->tables = static_cast<unsigned long long*>(v);
+    rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)(2 * nb) * (size_t)nslots);
+    s->counts = static_cast<int32_t*>(v);
+    if (rc == SPP_OK && hipMemset(s->counts, 0, sizeof(int32_t) * (size_t)(2 * nb) * (size_t)nslots) != hipSuccess) {
+      set_error("spp_sampler_create: hipMemset failed");
+      rc = SPP_ERR_HIP;
+    }
   }
   if (rc == SPP_OK && hipHostMalloc((void**)&s->h_states, sizeof(SlotState) * (size_t)nslots, hipHostMallocDefault) !=
                           hipSuccess) {
@@ -635,28 +819,31 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     A(p.rng[1], uint32_t, s->dcap + kMtSlack);
     A(p.bsum0, int32_t, nblk_max);
     A(p.bsum1, int32_t, nblk_max);
+    A(p.known, unsigned long long, (int64_t)nb * s->geom.kcap);
+    A(p.boff, int32_t, nb + 1);
+    A(p.bcur, int32_t, nb);
     for (int h = 0; h < H; ++h) {
       A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
       A(p.out_col[h], int32_t, s->ecap[h]);
       sl.ecap_dyn[h] = s->ecap[h];
     }
 #undef A
-    p.table = s->tables + (size_t)i * tab;
-    p.tab_mask = tab - 1;
+    p.kcount = s->counts + (size_t)i * 2 * nb;
+    p.bcount = p.kcount + nb;
     p.st = s->d_states + i;
     sl.host_state = s->h_states + i;
     // per-edge temporaries are separately allocated so the generic path can grow them
     if (rc == SPP_OK) {
       sl.etmp_cap = etmp;
       hipError_t e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
-      if (e == hipSuccess) e = hipMalloc((void**)&p.eslot, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.bpairs, sizeof(unsigned long long) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.erank, sizeof(int32_t) * (size_t)etmp);
       if (e != hipSuccess) {
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
       }
-      s->bytes += 16 * etmp;
+      s->bytes += 20 * etmp;
     }
     if (rc == SPP_OK && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
       set_error("spp_sampler_create: hipEventCreate failed");
@@ -686,7 +873,7 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   for (auto& sl : s->slots) {
     if (sl.done) (void)hipEventDestroy(sl.done);
     if (sl.p.cval) (void)hipFree(sl.p.cval);
-    if (sl.p.eslot) (void)hipFree(sl.p.eslot);
+    if (sl.p.bpairs) (void)hipFree(sl.p.bpairs);
     if (sl.p.evals) (void)hipFree(sl.p.evals);
     if (sl.p.erank) (void)hipFree(sl.p.erank);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
@@ -710,13 +897,18 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
   bool changed = false;
   if (need > sl.etmp_cap) {
     int64_t cap = std::max(need, sl.etmp_cap * 2);
-    (void)hipFree(sl.p.cval); (void)hipFree(sl.p.eslot); (void)hipFree(sl.p.evals); (void)hipFree(sl.p.erank);
-    sl.p.cval = nullptr; sl.p.eslot = nullptr; sl.p.evals = nullptr; sl.p.erank = nullptr;
+    // erank is preserved: it still holds the previous hop's ranks, which k_bucket_dedup needs
+    int32_t* old_erank = sl.p.erank;
+    const int64_t old_cap = sl.etmp_cap;
+    (void)hipFree(sl.p.cval); (void)hipFree(sl.p.bpairs); (void)hipFree(sl.p.evals);
+    sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.erank = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMalloc((void**)&sl.p.eslot, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.erank, sizeof(int32_t) * (size_t)cap));
-    s->bytes += 16 * (cap - sl.etmp_cap);
+    SPP_HIP_TRY(hipMemcpy(sl.p.erank, old_erank, sizeof(int32_t) * (size_t)old_cap, hipMemcpyDeviceToDevice));
+    (void)hipFree(old_erank);
+    s->bytes += 20 * (cap - sl.etmp_cap);
     sl.etmp_cap = cap;
     changed = true;
   }
@@ -780,8 +972,11 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const unsigned gy = (unsigned)n;
   SlotHost& lead = s->slots[(size_t)first_slot];
 
-  SPP_HIP_TRY(hipMemsetAsync(lead.p.table, 0xFF, sizeof(unsigned long long) * (size_t)s->tab_size * (size_t)n, st));
-  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)ceil_div(max_seeds, kNT), gy), dim3(kNT), 0, st, s->d_slots, ga);
+  const DedupGeom geom = s->geom;
+  // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
+  SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb) * (size_t)n, st));
+  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)ceil_div(max_seeds, kNT), gy), dim3(kNT), 0, st, s->d_slots, ga,
+                     geom);
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
@@ -808,6 +1003,17 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h, f,
                          replace);
     }
+    // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
+    const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
+    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, geom);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
+    if (s->lds_log2 == 13)
+      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
+                         geom);
+    else
+      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
+                         geom);
     hipLaunchKernelGGL(k_hop_flag, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
     hipLaunchKernelGGL(k_hop_scan2, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f,
                        (int32_t)s->tcap[H]);
@@ -956,7 +1162,7 @@ extern "C" spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_cou
   SPP_HIP_TRY(hipEventSynchronize(sl.wait_on));
   sl.waited = true;
   if (sl.host_state->error) {
-    set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws)",
+    set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws 8=dedup bucket)",
               sl.host_state->error);
     return SPP_ERR_CAPACITY;
   }
