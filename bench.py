@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-products"))
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "24")))
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "16")))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-step", action="store_true",

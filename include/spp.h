@@ -125,6 +125,10 @@ spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
 void spp_sampler_destroy(spp_sampler* s);
 /* bytes of HBM workspace held by the sampler (all slots) */
 int64_t spp_sampler_workspace_bytes(const spp_sampler* s);
+/* A persistent HIP stream owned by the sampler that the consumer may use for spp_session_export /
+ * spp_sampler_export / spp_sampler_gather (as a hipStream_t).  Using it keeps the per-batch delivery
+ * kernel on a hardware queue of its own; any other stream works too. */
+void* spp_sampler_deliver_stream(spp_sampler* s);
 /* the configuration the sampler was created with */
 spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out);
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "spp_sampler_create": (C.c_int, [C.POINTER(SamplerCfg), C.POINTER(p)]),
     "spp_sampler_destroy": (None, [p]),
     "spp_sampler_workspace_bytes": (i64, [p]),
+    "spp_sampler_deliver_stream": (p, [p]),
     "spp_sampler_get_cfg": (C.c_int, [p, C.POINTER(SamplerCfg)]),
     "spp_sampler_sample": (C.c_int, [p, i32, p, i64, u32, i64, p]),
     "spp_sampler_wait": (C.c_int, [p, i32, C.POINTER(MfgCounts)]),

@@ -62,7 +62,8 @@ struct DedupGeom {
 };
 constexpr int kMaxBucketsLog2 = 12;
 constexpr int kMaxBuckets = 1 << kMaxBucketsLog2;
-constexpr int kBucketTile = 4096;           // edges one workgroup partitions per pass
+constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
+                                            // one global atomic reserves room for several edges)
 constexpr uint32_t kPending = 0x80000000u;  // known-list value = kPending | edge position of the previous hop
 
 // device-resident bookkeeping of one batch slot (copied to pinned host memory after sampling)
@@ -484,9 +485,16 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   }
   if (!work) return;
   __syncthreads();
-  for (int i = e0 + threadIdx.x; i < e1; i += kNT) {
-    const unsigned long long pr = s.bpairs[i];
-    lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr >> 32), T + (uint32_t)pr, &ovf);
+  for (int i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * kNT) {  // 4 independent loads in flight per lane
+    unsigned long long pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kNT;
+      pr[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (pr[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
   }
   __syncthreads();
   if (ovf) {
@@ -704,10 +712,15 @@ struct spp_sampler {
   bool generic[SPP_MAX_HOPS];
   bool any_generic = false;
   DedupGeom geom{};
-  int lds_log2 = 13;                // LDS table slots of k_bucket_dedup (13: 64 KB, 14: 128 KB)
+  int lds_log2 = 12;                // LDS table slots of k_bucket_dedup (12: 32 KB, 13: 64 KB, 14: 128 KB)
   int64_t bytes = 0;
   std::vector<SlotHost> slots;
   std::vector<void*> allocs;
+  // Streams live as long as the sampler (HIP maps streams onto a handful of hardware queues in
+  // creation order; creating them once, back to back, keeps the delivery stream and the sampling
+  // streams on distinct queues for the whole run instead of re-rolling the mapping every epoch).
+  hipStream_t deliver_stream = nullptr;
+  hipStream_t work_streams[kMaxWorkStreams] = {};
   SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
@@ -767,14 +780,16 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     delete s;
     return SPP_ERR_INVALID;
   }
-  // dedup geometry: ~3k distinct nodes per bucket at the worst case, LDS table of 8k (or 16k) slots
+  // dedup geometry: <= ~1.5k distinct nodes per bucket at the worst case so that a 4096-slot LDS
+  // table (32 KB, 4-5 workgroups per CU) stays under 40 % load; larger tables only when the bucket
+  // count is capped
   int nb_log2 = 0;
-  while (nb_log2 < kMaxBucketsLog2 && (ucap >> nb_log2) > 3072) ++nb_log2;
+  while (nb_log2 < kMaxBucketsLog2 && (ucap >> nb_log2) > 1536) ++nb_log2;
   s->geom.nb_log2 = nb_log2;
   s->geom.nb = 1 << nb_log2;
   const int64_t per_bucket = (ucap + s->geom.nb - 1) / s->geom.nb;
   s->geom.kcap = (int32_t)std::min<int64_t>(per_bucket + per_bucket / 2 + 256, 0x7fffffff);
-  s->lds_log2 = per_bucket > 4096 ? 14 : 13;
+  s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 2048 ? 13 : 12);
   const int nb = s->geom.nb;
   int64_t tmax = 0;
   for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
@@ -850,6 +865,9 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       rc = SPP_ERR_HIP;
     }
   }
+  if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) rc = SPP_ERR_HIP;
+  // work streams are created on first use, right after this one (only as many as slot-sets are used)
+  if (rc == SPP_ERR_HIP) set_error("spp_sampler_create: stream creation failed");
   if (rc == SPP_OK) {
     std::vector<SlotPtrs> tmp((size_t)nslots);
     for (int i = 0; i < nslots; ++i) tmp[(size_t)i] = s->slots[(size_t)i].p;
@@ -879,11 +897,16 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
   if (s->h_states) (void)hipHostFree(s->h_states);
+  if (s->deliver_stream) (void)hipStreamDestroy(s->deliver_stream);
+  for (auto st : s->work_streams)
+    if (st) (void)hipStreamDestroy(st);
   for (void* a : s->allocs) (void)hipFree(a);
   delete s;
 }
 
 extern "C" int64_t spp_sampler_workspace_bytes(const spp_sampler* s) { return s ? s->bytes : 0; }
+
+extern "C" void* spp_sampler_deliver_stream(spp_sampler* s) { return s ? (void*)s->deliver_stream : nullptr; }
 
 extern "C" spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out) {
   SPP_REQUIRE(s && out, "spp_sampler_get_cfg: NULL argument");
@@ -929,6 +952,12 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
 namespace spp {
 
 int sampler_max_group(const spp_sampler* s) { return s->any_generic ? 1 : kMaxGroup; }
+
+hipStream_t sampler_work_stream(spp_sampler* s, int i) {
+  hipStream_t& st = s->work_streams[i % kMaxWorkStreams];
+  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;  // null stream as last resort
+  return st;
+}
 
 // mt19937 streams of a group of batches into rng[buf] of their slots
 spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, const uint32_t* seeds,
@@ -1008,7 +1037,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
     hipLaunchKernelGGL(k_bucket_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, geom);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
-    if (s->lds_log2 == 13)
+    if (s->lds_log2 == 12)
+      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
+                         geom);
+    else if (s->lds_log2 == 13)
       hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
                          geom);
     else

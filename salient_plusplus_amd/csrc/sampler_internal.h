@@ -5,10 +5,14 @@
 
 namespace spp {
 
-constexpr int kMaxGroup = 16;  // batches one launch can process (blockIdx.y)
+constexpr int kMaxGroup = 16;       // batches one launch can process (blockIdx.y)
+constexpr int kMaxWorkStreams = 4;  // sampling streams owned by a sampler (one per slot-set in flight)
 
 // largest group the sampler supports (1 when a hop takes the generic path)
 int sampler_max_group(const spp_sampler* s);
+
+// the sampler's i-th sampling stream (persistent; i is taken modulo kMaxWorkStreams)
+hipStream_t sampler_work_stream(spp_sampler* s, int i);
 
 // Generate the mt19937 streams of `n` batches (slots first_slot..first_slot+n-1) into RNG buffer
 // `buf` (0/1) of their slots: draws [skip, skip + Dcap) of mt19937(seed).

@@ -35,7 +35,7 @@ struct spp_session {
   int G = 1;                 // batches per group
   int num_sets = 1;          // slot-sets in flight
   int64_t num_groups = 0;    // groups in this epoch
-  std::vector<hipStream_t> streams;      // one per slot-set
+  std::vector<hipStream_t> streams;      // one per slot-set (borrowed from the sampler)
   std::vector<hipEvent_t> export_done;   // per slot
   std::vector<char> export_recorded;     // per slot
   int64_t chain_launched = 0;            // groups whose sampling chain was launched
@@ -155,7 +155,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 3));
   G = std::min(G, std::min(M, kMaxGroup));
   if (generic) G = 1;
-  int sets = std::max(1, M / G);
+  int sets = std::max(1, std::min(M / G, kMaxWorkStreams));
 
   spp_status rc = SPP_OK;
   if (cfg->sampler) {
@@ -201,14 +201,8 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
       rc = SPP_ERR_HIP;
     }
   };
-  auto mk_stream = [&](hipStream_t* st) {
-    if (rc == SPP_OK && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) {
-      set_error("spp_session_create: hipStreamCreate failed");
-      rc = SPP_ERR_HIP;
-    }
-  };
   s->streams.assign((size_t)sets, nullptr);
-  for (auto& st : s->streams) mk_stream(&st);
+  for (int i = 0; i < sets; ++i) s->streams[(size_t)i] = sampler_work_stream(s->sampler, i);
   s->export_done.assign((size_t)(sets * G), nullptr);
   s->export_recorded.assign((size_t)(sets * G), 0);
   for (auto& e : s->export_done) mk_event(&e);
@@ -229,8 +223,6 @@ extern "C" void spp_session_destroy(spp_session* s) {
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
   for (auto ev : s->export_done)
     if (ev) (void)hipEventDestroy(ev);
-  for (auto st : s->streams)
-    if (st) (void)hipStreamDestroy(st);
   delete s;
 }
 

@@ -29,7 +29,7 @@ from .. import _native as nat
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
            "multilayer_sample", "full_sample", "to_row_major", "serial_index"]
 
-_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "24"))
+_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "16"))
 
 
 # --------------------------------------------------------------------------------------------
@@ -371,6 +371,7 @@ class Session:
             raise
         self._h = h
         self._desc = nat.BatchDesc()
+        self._consumer_stream = None
         self._e_id = torch.empty(0, dtype=torch.int64, device=self._dev)
         # (src pointer, rows, row bytes) of the resident feature / label matrices, built once
         self._x_args = (C.c_void_p(self._x.data_ptr()), self._x.size(0), self._x.size(1) * self._x.element_size()) \
@@ -399,6 +400,16 @@ class Session:
             self.close()
         except Exception:
             pass
+
+    @property
+    def consumer_stream(self):
+        """The sampler's persistent delivery stream as a torch stream: exporting batches on it keeps
+        the per-batch delivery kernel on a hardware queue that no sampling stream shares."""
+        if self._consumer_stream is None:
+            ptr = self._L.spp_sampler_deliver_stream(self._pool_entry[0])
+            self._consumer_stream = torch.cuda.ExternalStream(ptr, device=self._dev) if ptr else \
+                torch.cuda.Stream(self._dev)
+        return self._consumer_stream
 
     # ---- properties of fast_sampler.cpp:1325-1338 ----
     @property

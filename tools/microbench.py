@@ -80,5 +80,35 @@ def main():
         L.spp_sampler_destroy(h)
 
 
+def chain_only():
+    """Sampling throughput with the consumer side switched off (batches are dropped, never exported)."""
+    wl = make_workload(os.environ.get("WL", "S-products"), device=dev)
+    torch.cuda.synchronize()
+    for slots, group in ((24, 8), (16, 8), (32, 16), (12, 4)):
+        cfg = nat.SessionCfg()
+        cfg.rowptr_dev, cfg.col_dev = wl.rowptr.data_ptr(), wl.col.data_ptr()
+        cfg.num_nodes, cfg.nnz = wl.num_nodes, wl.col.numel()
+        cfg.idx_dev, cfg.n_idx = wl.train_idx.data_ptr(), wl.train_idx.numel()
+        cfg.batch_size, cfg.num_hops = wl.batch_size, len(wl.fanouts)
+        for i, f in enumerate(wl.fanouts):
+            cfg.sizes[i] = f
+        cfg.force_exact_num_batches, cfg.exact_num_batches = 1, wl.train_idx.numel() // wl.batch_size
+        cfg.max_items_in_queue, cfg.group_size, cfg.device = slots, group, 0
+        h = C.c_void_p()
+        nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
+        d = nat.BatchDesc()
+        n = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while L.spp_session_next(h, C.byref(d)) == 1:
+            n += 1
+        dt = time.perf_counter() - t0
+        print(f"chain only: slots={slots} group={group}: {n} batches, {dt/n*1e6:.1f} us/batch", flush=True)
+        L.spp_session_destroy(h)
+
+
 if __name__ == "__main__":
+    if "chain" in sys.argv[1:]:
+        chain_only()
+        sys.exit(0)
     main()
