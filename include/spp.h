@@ -219,7 +219,7 @@ typedef struct spp_session_cfg {
   int32_t force_exact_num_batches;
   int64_t exact_num_batches;
   int32_t max_items_in_queue;      /* upper bound on batches in flight (slots) */
-  int32_t group_size;              /* batches sampled per launch sequence (0 = auto: max_items/3, <= 8);
+  int32_t group_size;              /* batches sampled per launch sequence (0 = auto: max_items/2, <= 8);
                                       max_items_in_queue / group_size slot-sets are in flight, one HIP
                                       stream each */
   int32_t device;

@@ -37,6 +37,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "gather_body.cuh"
@@ -954,7 +955,12 @@ namespace spp {
 int sampler_max_group(const spp_sampler* s) { return s->any_generic ? 1 : kMaxGroup; }
 
 hipStream_t sampler_work_stream(spp_sampler* s, int i) {
-  hipStream_t& st = s->work_streams[i % kMaxWorkStreams];
+  static const int n_streams = [] {
+    const char* e = getenv("SPP_WORK_STREAMS");
+    const int v = e ? atoi(e) : 2;  // two sampling streams measured best (1: -22 %, 3: queues get shared)
+    return v < 1 ? 1 : (v > kMaxWorkStreams ? kMaxWorkStreams : v);
+  }();
+  hipStream_t& st = s->work_streams[i % n_streams];
   if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;  // null stream as last resort
   return st;
 }

@@ -20,6 +20,10 @@
 #include "spp_internal.h"
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -38,7 +42,17 @@ struct spp_session {
   std::vector<hipStream_t> streams;      // one per slot-set (borrowed from the sampler)
   std::vector<hipEvent_t> export_done;   // per slot
   std::vector<char> export_recorded;     // per slot
-  int64_t chain_launched = 0;            // groups whose sampling chain was launched
+  int64_t chain_launched = 0;            // groups whose sampling chain was launched (guarded by mu)
+  // Launcher thread: enqueues the ~40 kernel launches of a group's chain off the consumer thread
+  // (they cost 0.2-0.5 ms of host time per group, which used to stall the consumer at every group
+  // boundary).  It is the counterpart of the reference's worker threads, with the GPU doing the work.
+  std::thread launcher;
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t groups_consumed = 0;           // groups fully consumed by the caller (guarded by mu)
+  bool stop = false;
+  spp_status launch_rc = SPP_OK;
+  std::string launch_err;
   int64_t next_to_deliver = 0;           // batch index
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
   int64_t blocked_us = 0;
@@ -124,13 +138,46 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
   return SPP_OK;
 }
 
-// keep the pipeline full: chains for up to num_sets groups beyond the ones fully consumed
-static spp_status pump(spp_session* s, int64_t groups_fully_consumed) {
-  while (s->chain_launched < s->num_groups && s->chain_launched < groups_fully_consumed + s->num_sets) {
-    SPP_TRY(launch_group_chain(s, s->chain_launched));
-    s->chain_launched++;
+// Launcher thread body: keep chains in flight for up to num_sets groups beyond the ones fully consumed.
+static void launcher_main(spp_session* s) {
+  (void)hipSetDevice(s->cfg.device);
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    s->cv.wait(lk, [s] {
+      return s->stop || (s->launch_rc == SPP_OK && s->chain_launched < s->num_groups &&
+                         s->chain_launched < s->groups_consumed + s->num_sets);
+    });
+    if (s->stop) return;
+    const int64_t g = s->chain_launched;
+    lk.unlock();
+    const spp_status rc = launch_group_chain(s, g);  // touches only slots of group g's slot-set
+    lk.lock();
+    if (rc != SPP_OK) {
+      s->launch_rc = rc;
+      s->launch_err = spp_last_error();
+    } else {
+      s->chain_launched = g + 1;
+    }
+    s->cv.notify_all();
   }
-  return SPP_OK;
+}
+
+// consumer side: a whole group has been consumed -> its slot-set may be reused
+static void notify_group_consumed(spp_session* s, int64_t groups_fully_consumed) {
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->groups_consumed = groups_fully_consumed;
+  }
+  s->cv.notify_all();
+}
+
+// consumer side: block until the chain of group g has been enqueued (its completion event exists)
+static spp_status wait_group_launched(spp_session* s, int64_t g) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->cv.wait(lk, [s, g] { return s->chain_launched > g || s->launch_rc != SPP_OK; });
+  if (s->chain_launched > g) return SPP_OK;
+  set_error("%s", s->launch_err.c_str());
+  return s->launch_rc;
 }
 
 extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session** out) {
@@ -152,7 +199,9 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 
   bool generic = false;
   for (int h = 0; h < cfg->num_hops; ++h) generic |= (cfg->sizes[h] < 0 || cfg->sizes[h] > 32);
-  int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 3));
+  // auto: two slot-sets of up to 8 batches (each set-stream then owns a hardware queue; measured
+  // best on MI355X: 16 slots = 2 x 8), smaller groups only when fewer slots are allowed
+  int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 2));
   G = std::min(G, std::min(M, kMaxGroup));
   if (generic) G = 1;
   int sets = std::max(1, std::min(M / G, kMaxWorkStreams));
@@ -206,7 +255,10 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   s->export_done.assign((size_t)(sets * G), nullptr);
   s->export_recorded.assign((size_t)(sets * G), 0);
   for (auto& e : s->export_done) mk_event(&e);
-  if (rc == SPP_OK) rc = pump(s, 0);  // prime the pipeline
+  if (rc == SPP_OK) {
+    s->launcher = std::thread(launcher_main, s);  // primes the pipeline right away
+    if (s->num_groups > 0) rc = wait_group_launched(s, 0);
+  }
   if (rc != SPP_OK) {
     spp_session_destroy(s);
     return rc;
@@ -217,6 +269,14 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 
 extern "C" void spp_session_destroy(spp_session* s) {
   if (!s) return;
+  if (s->launcher.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->stop = true;
+    }
+    s->cv.notify_all();
+    s->launcher.join();
+  }
   (void)hipSetDevice(s->cfg.device);
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
@@ -248,7 +308,7 @@ static spp_status retire_current(spp_session* s) {
   s->current_slot = -1;
   const int64_t g = b / s->G;
   const bool last_of_group = (b + 1 == (int64_t)s->ranges.size()) || ((b + 1) % s->G == 0);
-  if (last_of_group) return pump(s, g + 1);
+  if (last_of_group) notify_group_consumed(s, g + 1);
   return SPP_OK;
 }
 
@@ -266,7 +326,8 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   const int64_t g = b / s->G;
   const int32_t slot = (int32_t)((g % s->num_sets) * s->G + b % s->G);
   const auto t0 = std::chrono::steady_clock::now();
-  spp_status rc = spp_sampler_wait(s->sampler, slot, &out->counts);
+  spp_status rc = wait_group_launched(s, g);
+  if (rc == SPP_OK) rc = spp_sampler_wait(s->sampler, slot, &out->counts);
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   if (us > 50) {  // the reference counts only waits that actually spun (fast_sampler.cpp:788-799)
     s->blocked_us += us;
