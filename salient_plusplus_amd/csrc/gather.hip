@@ -9,12 +9,12 @@
 
 namespace spp {
 
-template <int VEC, typename IdxT>
+template <int VEC, typename IdxT, bool kNT>
 __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(const char* __restrict__ src,
                                                                  const IdxT* __restrict__ idx, int64_t n,
                                                                  int64_t row_bytes, int chunks, int lpr_log2,
                                                                  char* __restrict__ dst) {
-  gather_rows_body<VEC, IdxT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x);
+  gather_rows_body<VEC, IdxT, kNT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x);
 }
 
 template <typename IdxT>
@@ -27,9 +27,16 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* 
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
   const int prof = prof_begin(SPP_PROF_GATHER, st, n);
-#define SPP_LAUNCH_GATHER(V)                                                                              \
-  hipLaunchKernelGGL((k_gather_rows<V, IdxT>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, idx, n, \
-                     row_bytes, chunks, lpr_log2, d)
+  static const bool nt = [] { const char* e = getenv("SPP_GATHER_NT"); return e ? atoi(e) != 0 : false; }();
+#define SPP_LAUNCH_GATHER(V)                                                                                    \
+  do {                                                                                                          \
+    if (nt)                                                                                                     \
+      hipLaunchKernelGGL((k_gather_rows<V, IdxT, true>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s,  \
+                         idx, n, row_bytes, chunks, lpr_log2, d);                                               \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_gather_rows<V, IdxT, false>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, \
+                         idx, n, row_bytes, chunks, lpr_log2, d);                                               \
+  } while (0)
   switch (gg.vec) {
     case 16: SPP_LAUNCH_GATHER(16); break;
     case 8: SPP_LAUNCH_GATHER(8); break;

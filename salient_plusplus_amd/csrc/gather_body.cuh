@@ -6,6 +6,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -41,13 +42,21 @@ static inline GatherGeom gather_geometry(const void* src, const void* dst, int64
   const int gpb = kGatherThreads >> g.lpr_log2;
   const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
   g.grid = (n + rows_per_iter - 1) / rows_per_iter;
-  const int64_t max_grid = 256 * 16;  // 256 CUs x 16 workgroups: grid-stride beyond that
+  static const int64_t max_grid = [] {  // 256 CUs x k workgroups: grid-stride beyond that
+    const char* e = getenv("SPP_GATHER_WG_PER_CU");
+    const int k = e ? atoi(e) : 16;
+    return (int64_t)256 * (k < 1 ? 1 : k);
+  }();
   if (g.grid > max_grid) g.grid = max_grid;
   if (g.grid < 1) g.grid = 1;
   return g;
 }
 
-template <int VEC, typename IdxT>
+// kNT: non-temporal loads of the source rows.  Measured on MI355X (770k random 200-B rows of a
+// 490 MB table, sustained): plain loads 63 us, non-temporal loads 88-93 us -- the rows are not
+// really read-once (hub rows repeat across batches and MALL/L2 catch them), so plain is the default;
+// the stores stay non-temporal.
+template <int VEC, typename IdxT, bool kNT = false>
 __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
                                                  int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
                                                  char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
@@ -73,7 +82,7 @@ __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, c
       V v[kGatherUnroll];
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u)
-        if (ok[u]) v[u] = __builtin_nontemporal_load(&s[u][c]);  // read-once rows: keep the node tables in MALL
+        if (ok[u]) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u)
         if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);

@@ -13,21 +13,25 @@
 // GPU formulation.  A launch processes a GROUP of up to 16 independent batches (blockIdx.y selects
 // the batch slot) so that even the small first hops put >> 256 workgroups on the chip.  Per hop
 // (T = nodes collected so far = targets; all counts stay on the device):
-//   k_hop_count   lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
-//   k_hop_scan    1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
-//   k_hop_pick    lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
-//                               col reads; node-table insert with atomicMin(T + edge position)
-//   k_hop_flag    lane/edge   : table value -> "is first occurrence" flag, workgroup flag sums
-//   k_hop_scan2   1 workgroup : scan of flag sums -> number of new nodes
-//   k_hop_assign  lane/edge   : rank of every first occurrence -> new local id, n_ids append,
-//                               table value finalised
-//   k_hop_rows    lane/target : local ids of the row, LDS rank-sort, out_col
+//   k_hop_count     lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
+//   k_hop_scan      1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
+//   k_hop_pick      lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
+//                                 col reads -> neighbour id of every edge position
+//   k_bucket_hist   tile/16k edges: edges per node-hash bucket; the last tile scans -> bucket offsets
+//   k_bucket_scatter tile       : (node, position) pairs regrouped by bucket (sequential traffic)
+//   k_bucket_dedup  workgroup/bucket: LDS table of the bucket's known nodes + candidates ->
+//                                 per edge: final local id, or T + earliest position of a new node
+//   k_hop_flag      lane/edge   : "is first occurrence" flags, workgroup flag sums
+//   k_hop_scan2     1 workgroup : scan of flag sums -> number of new nodes
+//   k_hop_assign    lane/edge   : rank of every first occurrence -> new local id, n_ids append
+//   k_hop_rows      lane/target : local ids of the row, LDS rank-sort, out_col
 // The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
 // one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
 // the ~0.5 ms serial recurrence never sits on the sampling critical path.
-// The node table is an open-addressing hash table in HBM (64-bit slots: key<<32 | value) sized
-// 2x the worst-case node count, so it stays Infinity-Cache resident; value < T means "final local
-// id", value >= T means "T + position of the earliest edge that reaches this node in this hop".
+// The node table is radix-partitioned: 64-bit entries (key<<32 | value) live in per-bucket LDS tables
+// for the duration of one k_bucket_dedup workgroup and, between hops, in compact per-bucket known
+// lists in HBM; value < T means "final local id", value >= T means "T + position of the earliest
+// edge that reaches this node in this hop".
 //
 // Hops with fanout < 0 (all neighbours) or fanout > 32 take a generic path (edge-parallel expand,
 // hipcub segmented sort, one host sync per hop to size the launch); such samplers run one batch
@@ -93,6 +97,7 @@ struct SlotPtrs {
   uint32_t* rng[2];    // draws rng_skip .. of the batch stream (ping-pong: generated one group ahead)
   int32_t* bsum0;
   int32_t* bsum1;
+  int32_t* ctr;        // "last workgroup" ticket counter (zero between launches)
   SlotState* st;
   int32_t* out_rowptr[SPP_MAX_HOPS];  // processing order
   int32_t* out_col[SPP_MAX_HOPS];
@@ -213,6 +218,26 @@ __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t re
   // sample_cpu.hpp:67-73 (f < 0: all), :91-94 (deg <= f: all), :97-110 (Floyd: f picks)
   smp = (f >= 0 && deg > f) ? 1 : 0;
   cnt = smp ? f : (deg > 0 ? deg : 0);
+}
+
+// ---- "last workgroup finishes the job" ---------------------------------------------------------
+// Producer workgroups publish partial results with device-scope atomics, drain them (s_waitcnt
+// vmcnt(0)), take a ticket from a device-scope counter, and the workgroup that draws the last ticket
+// reads the partials back with agent-scope atomic loads and finishes the job: the placement-independent
+// 8-byte-granule hand-off of cdna_hip_programming.md G16 (atomics on both sides).  Only used where few
+// workgroups take tickets (k_bucket_hist: one per 16k edges): with one ticket per 256 elements the
+// same-address atomics and their round trip made k_hop_count / k_hop_flag slower than a separate
+// single-workgroup scan launch (measured: sampling alone 76 -> 113 us/batch), so those keep k_hop_scan*.
+__device__ __forceinline__ int32_t acquire_i32(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// called by thread 0 once every wave of the workgroup has drained its atomics and passed a barrier
+__device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expected) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int32_t t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool last = (t == expected - 1);
+  if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return last;
 }
 
 __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, int32_t first_slot,
@@ -374,10 +399,13 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 __global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
                                                       DedupGeom g) {
   __shared__ int32_t lh[kMaxBuckets];
+  __shared__ int32_t lscan[kNT / kWave + 1];
+  __shared__ int is_last;
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
-  const int32_t E = s.st->E[h];
+  const int32_t E = s.st->error ? 0 : s.st->E[h];
   const int64_t base = (int64_t)blockIdx.x * kBucketTile;
-  if (base >= E || s.st->error) return;
+  if (base >= E && blockIdx.x != 0) return;  // tile 0 always takes part (E may be 0)
+  const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
   for (int b = threadIdx.x; b < g.nb; b += kNT) lh[b] = 0;
   __syncthreads();
   for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
@@ -386,20 +414,19 @@ __global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict_
   }
   __syncthreads();
   for (int b = threadIdx.x; b < g.nb; b += kNT)
-    if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);
-}
-
-// exclusive scan of the bucket counts -> offsets and scatter cursors; the counts are re-zeroed
-__global__ __launch_bounds__(kScanNT) void k_bucket_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                          DedupGeom g) {
-  __shared__ int32_t lds[kScanNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+    if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
+  // last tile: exclusive scan of the bucket counts -> offsets and scatter cursors; counts re-zeroed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own atomics before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = take_ticket_is_last(s.ctr, ntiles > 0 ? ntiles : 1) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
   int32_t carry = 0;
-  for (int32_t base = 0; base < g.nb; base += kScanNT) {
-    const int32_t b = base + threadIdx.x;
-    const int32_t v = (b < g.nb) ? s.bcount[b] : 0;
+  for (int32_t bb = 0; bb < g.nb; bb += kNT) {
+    const int32_t b = bb + threadIdx.x;
+    const int32_t v = (b < g.nb) ? acquire_i32(&s.bcount[b]) : 0;
     int32_t tot;
-    const int32_t ex = block_exclusive_scan<int32_t, kScanNT>(v, lds, &tot);
+    const int32_t ex = block_exclusive_scan<int32_t, kNT>(v, lscan, &tot);
     if (b < g.nb) {
       s.boff[b] = carry + ex;
       s.bcur[b] = carry + ex;
@@ -725,7 +752,7 @@ struct spp_sampler {
   SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
-  int32_t* counts = nullptr;         // [slot][2*nb]: kcount then bcount (zeroed per batch with one memset)
+  int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
 };
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -807,9 +834,9 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     s->d_states = static_cast<SlotState*>(v);
   }
   if (rc == SPP_OK) {
-    rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)(2 * nb) * (size_t)nslots);
+    rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)(2 * nb + 1) * (size_t)nslots);
     s->counts = static_cast<int32_t*>(v);
-    if (rc == SPP_OK && hipMemset(s->counts, 0, sizeof(int32_t) * (size_t)(2 * nb) * (size_t)nslots) != hipSuccess) {
+    if (rc == SPP_OK && hipMemset(s->counts, 0, sizeof(int32_t) * (size_t)(2 * nb + 1) * (size_t)nslots) != hipSuccess) {
       set_error("spp_sampler_create: hipMemset failed");
       rc = SPP_ERR_HIP;
     }
@@ -844,8 +871,9 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       sl.ecap_dyn[h] = s->ecap[h];
     }
 #undef A
-    p.kcount = s->counts + (size_t)i * 2 * nb;
+    p.kcount = s->counts + (size_t)i * (2 * nb + 1);
     p.bcount = p.kcount + nb;
+    p.ctr = p.bcount + nb;
     p.st = s->d_states + i;
     sl.host_state = s->h_states + i;
     // per-edge temporaries are separately allocated so the generic path can grow them
@@ -1009,7 +1037,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 
   const DedupGeom geom = s->geom;
   // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
-  SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb) * (size_t)n, st));
+  SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
   hipLaunchKernelGGL(k_seed_init, dim3((unsigned)ceil_div(max_seeds, kNT), gy), dim3(kNT), 0, st, s->d_slots, ga,
                      geom);
   for (int h = 0; h < H; ++h) {
@@ -1041,7 +1069,6 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
     hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, geom);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
     if (s->lds_log2 == 12)
       hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,

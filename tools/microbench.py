@@ -19,7 +19,7 @@ def P(t):
     return C.c_void_p(t.data_ptr())
 
 
-def timeit(fn, n=20, warm=3):
+def timeit(fn, n=300, warm=50):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
