@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPP_ABI_VERSION 1
+#define SPP_ABI_VERSION 2
 #define SPP_MAX_HOPS 8
 #define SPP_MAX_PARTS 64
 
@@ -88,6 +88,20 @@ spp_status spp_to_row_major(const void* src_dev, int64_t rows, int64_t cols, int
  * ------------------------------------------------------------------------- */
 typedef struct spp_sampler spp_sampler;
 
+/* Optional ownership bucketing of the batch's node list, fused into the sampling chain (worker
+ * distributed branch, fast_sampler.cpp:1017-1272): with num_parts > 0 every sampled batch also
+ * carries the per-owner id lists, the VIP-cache hits and perm_partition_to_mfg, and their sizes
+ * arrive with the counts -- no extra launch sequence and no host synchronisation per batch. */
+typedef struct spp_partition_cfg {
+  int32_t num_parts;                    /* P; 0 = bucketing off                                  */
+  int32_t rank;                         /* this process's partition                              */
+  int64_t offsets[SPP_MAX_PARTS + 1];   /* RangePartitionBook offsets (range_partition_book.cpp:38-55) */
+  int32_t use_cache;                    /* Config.use_cache (fast_sampler.cpp:1108)               */
+  const int32_t* cache_map_dev;         /* int32[cache_map_len]: node -> cache row, -1 = miss
+                                           (spp_cache_build_map); read while batches are in flight */
+  int64_t cache_map_len;
+} spp_partition_cfg;
+
 typedef struct spp_sampler_cfg {
   const int64_t* rowptr_dev;   /* int64[num_nodes+1], HBM resident           */
   const int64_t* col_dev;      /* int64[nnz], HBM resident                   */
@@ -100,6 +114,7 @@ typedef struct spp_sampler_cfg {
   int32_t device;              /* HIP device ordinal                         */
   int32_t replace;             /* 1: sample WITH replacement (sample_cpu.hpp:74-82; only the free
                                   sample_adj exposes it, multilayer_sample passes false) */
+  spp_partition_cfg part;      /* part.num_parts = 0: plain (single-GPU) batches */
 } spp_sampler_cfg;
 
 /* counts of one sampled batch; hops in OUTPUT order (outermost first, after the
@@ -112,6 +127,10 @@ typedef struct spp_mfg_counts {
   int64_t S[SPP_MAX_HOPS];        /* source nodes of hop                     */
   int64_t E[SPP_MAX_HOPS];        /* sampled edges of hop                    */
   int64_t draws;                  /* RNG outputs consumed                    */
+  /* with spp_partition_cfg.num_parts = P > 0: [0,P) nodes owned by partition m (cache hits
+   * excluded when use_cache), [P] cache hits, [P+1] reserved (host-resident local rows: always 0,
+   * every local row lives in HBM); else zeros */
+  int64_t part_counts[SPP_MAX_PARTS + 2];
 } spp_mfg_counts;
 
 /* caller-owned, exact-size destination buffers for one batch's MFG */
@@ -119,6 +138,11 @@ typedef struct spp_mfg_out {
   int64_t* n_id;                  /* int64[U]                                */
   int64_t* rowptr[SPP_MAX_HOPS];  /* int64[T_h+1], output order              */
   int64_t* col[SPP_MAX_HOPS];     /* int64[E_h],   output order              */
+  /* bucketing outputs (NULL = skip; ignored when the sampler has no spp_partition_cfg):          */
+  int64_t* parts;                 /* int64[sum part_counts[0..P)]: global node ids grouped by owner,
+                                     MFG order inside a group (fast_sampler.cpp:1063-1068)        */
+  int64_t* cached;                /* int64[part_counts[P]]: cache rows of the hits (:1256)         */
+  int64_t* perm;                  /* int64[U]: perm_partition_to_mfg (:1085, :1246-1252)           */
 } spp_mfg_out;
 
 spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
@@ -228,6 +252,9 @@ typedef struct spp_session_cfg {
    * reference's process-global worker pool that outlives Sessions (fast_sampler.cpp:512-513).
    * A borrowed sampler is not destroyed by spp_session_destroy. */
   spp_sampler* sampler;
+  /* Optional ownership bucketing (NULL = off).  With a borrowed sampler it must equal the
+   * sampler's own spp_partition_cfg. */
+  const spp_partition_cfg* part;
 } spp_session_cfg;
 
 typedef struct spp_batch_desc {

@@ -18,20 +18,26 @@ i64 = C.c_int64
 u32 = C.c_uint32
 
 
+class PartitionCfg(C.Structure):
+    _fields_ = [("num_parts", i32), ("rank", i32), ("offsets", i64 * (SPP_MAX_PARTS + 1)),
+                ("use_cache", i32), ("cache_map_dev", p), ("cache_map_len", i64)]
+
+
 class SamplerCfg(C.Structure):
     _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
                 ("num_hops", i32), ("sizes", i64 * SPP_MAX_HOPS), ("max_batch", i64),
-                ("num_slots", i32), ("device", i32), ("replace", i32)]
+                ("num_slots", i32), ("device", i32), ("replace", i32), ("part", PartitionCfg)]
 
 
 class MfgCounts(C.Structure):
     _fields_ = [("num_nodes", i64), ("num_seeds", i64), ("num_hops", i32),
                 ("T", i64 * SPP_MAX_HOPS), ("S", i64 * SPP_MAX_HOPS), ("E", i64 * SPP_MAX_HOPS),
-                ("draws", i64)]
+                ("draws", i64), ("part_counts", i64 * (SPP_MAX_PARTS + 2))]
 
 
 class MfgOut(C.Structure):
-    _fields_ = [("n_id", p), ("rowptr", p * SPP_MAX_HOPS), ("col", p * SPP_MAX_HOPS)]
+    _fields_ = [("n_id", p), ("rowptr", p * SPP_MAX_HOPS), ("col", p * SPP_MAX_HOPS),
+                ("parts", p), ("cached", p), ("perm", p)]
 
 
 class SessionCfg(C.Structure):
@@ -39,7 +45,8 @@ class SessionCfg(C.Structure):
                 ("idx_dev", p), ("n_idx", i64), ("batch_size", i64), ("num_hops", i32),
                 ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
                 ("force_exact_num_batches", i32), ("exact_num_batches", i64),
-                ("max_items_in_queue", i32), ("group_size", i32), ("device", i32), ("sampler", p)]
+                ("max_items_in_queue", i32), ("group_size", i32), ("device", i32), ("sampler", p),
+                ("part", C.POINTER(PartitionCfg))]
 
 
 class BatchDesc(C.Structure):
@@ -109,7 +116,7 @@ def load():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.spp_abi_version() != 1:
+        if L.spp_abi_version() != 2:
             raise SppError("libspp_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -6,22 +6,12 @@
 //   assembly             reference fast_trainer/transferers.py:472-486
 #include "spp_internal.h"
 
+#include "partition_common.cuh"
+
 namespace spp {
 
 constexpr int kPT = 256;
-constexpr int kMaxBuckets = SPP_MAX_PARTS + 2;  // P partitions + cache-hit bucket + host-local counter
-
-struct Offsets {
-  int32_t n;  // P + 1
-  int64_t v[SPP_MAX_PARTS + 1];
-};
-
-// searchsorted(offsets, nid, right=True) - 1   (range_partition_book.cpp:98-100)
-__device__ __forceinline__ int32_t owner_of(const Offsets& o, int64_t v) {
-  int32_t c = 0;
-  for (int32_t k = 0; k < o.n; ++k) c += (o.v[k] <= v) ? 1 : 0;
-  return c - 1;
-}
+constexpr int kMaxBuckets = kPartBuckets;
 
 __global__ __launch_bounds__(kPT) void k_nid2partid(Offsets o, const int64_t* __restrict__ nids, int64_t n,
                                                      int64_t* __restrict__ out) {

@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "gather_body.cuh"
+#include "partition_common.cuh"
 #include "mt19937.cuh"
 #include "sampler_internal.h"
 
@@ -79,6 +80,7 @@ struct SlotState {
   int64_t dbase[SPP_MAX_HOPS + 1]; // RNG draws consumed before hop h (relative to rng_skip)
   int32_t error;
   int32_t pad;
+  int32_t pcnt[kPartBuckets];      // ownership buckets of the node list (spp_partition_cfg): [0,P) owners, [P] cache hits
 };
 
 struct SlotPtrs {
@@ -101,6 +103,12 @@ struct SlotPtrs {
   SlotState* st;
   int32_t* out_rowptr[SPP_MAX_HOPS];  // processing order
   int32_t* out_col[SPP_MAX_HOPS];
+  // ownership bucketing (spp_partition_cfg; NULL when off)
+  int32_t* parts;      // [Ucap] node ids grouped by owner, then (separately) ...
+  int32_t* pcached;    // [Ucap] cache rows of the cache hits
+  int32_t* pperm;      // [Ucap] perm_partition_to_mfg
+  uint8_t* pbucket;    // [Ucap] bucket of every node
+  int32_t* pblk;       // [P+1][pnblk] per-workgroup bucket counts -> exclusive offsets
 };
 
 // per-launch description of a group of batches (passed by value)
@@ -648,13 +656,113 @@ __global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __rest
 }
 
 // ----------------------------------------------------------------------------------------------
+// ownership bucketing of the finished node list (worker distributed branch, fast_sampler.cpp:1017-1272)
+// ----------------------------------------------------------------------------------------------
+// Same three passes as the standalone spp_partition_batch (partition.hip), grouped over the batches
+// of a launch and reading the slot's int32 node list, so that the bucket sizes travel to the host
+// with the batch's other counts instead of costing a launch sequence + a blocking read per batch.
+struct PartDev {
+  Offsets off;
+  int32_t P, rank, use_cache;
+  const int32_t* cache_map;
+  int64_t cache_len;
+  int32_t nblk_cap;  // row pitch of pblk
+};
+
+__global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t H,
+                                                    PartDev a) {
+  __shared__ int32_t cnt[kPartBuckets];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t U = s.st->error ? 0 : s.st->cnt[H];
+  if ((int64_t)blockIdx.x * kNT >= U) return;
+  for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
+  __syncthreads();
+  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  if (i < U) {
+    const int32_t b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)s.n_ids[i]);
+    s.pbucket[i] = (uint8_t)b;
+    atomicAdd(&cnt[b], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + blockIdx.x] = cnt[k];
+}
+
+// one wavefront per bucket: exclusive scan of the bucket's per-workgroup counts
+__global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                        int32_t H, PartDev a) {
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  SlotState* st = s.st;
+  const int32_t U = st->error ? 0 : st->cnt[H];
+  const int32_t nblk = (U + kNT - 1) / kNT;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  for (int32_t m = wid; m <= a.P; m += kScanNT / kWave) {
+    int32_t* row = s.pblk + (int64_t)m * a.nblk_cap;
+    int32_t carry = 0;
+    for (int32_t base = 0; base < nblk; base += kWave) {
+      const int32_t i = base + lane;
+      const int32_t v = (i < nblk) ? row[i] : 0;
+      const int32_t inc = wave_inclusive_scan(v);
+      if (i < nblk) row[i] = carry + inc - v;
+      carry += __shfl(inc, kWave - 1, kWave);
+    }
+    if (lane == 0) st->pcnt[m] = carry;
+  }
+  if (threadIdx.x == 0) st->pcnt[a.P + 1] = 0;  // every local row is HBM resident
+}
+
+__global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                       int32_t H, PartDev a) {
+  __shared__ int32_t wcnt[kNT / kWave][kPartBuckets];
+  __shared__ int32_t base[kPartBuckets];
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t U = s.st->error ? 0 : s.st->cnt[H];
+  if ((int64_t)blockIdx.x * kNT >= U) return;
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  for (int k = threadIdx.x; k < (kNT / kWave) * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
+  if (threadIdx.x == 0) {
+    int32_t acc = 0;
+    for (int m = 0; m <= a.P; ++m) {  // concat order: parts[0..P-1] then cache hits
+      base[m] = acc;
+      acc += s.st->pcnt[m];
+    }
+  }
+  __syncthreads();
+  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  const bool valid = i < U;
+  const int32_t b = valid ? (int32_t)s.pbucket[i] : -1;
+  // stable rank inside the wavefront among lanes of the same bucket
+  int32_t rank_w = 0;
+  unsigned long long todo = __ballot(valid);
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int32_t lb = __shfl(b, leader, kWave);
+    const unsigned long long m = __ballot(valid && b == lb);
+    if (valid && b == lb) {
+      rank_w = __popcll(m & below);
+      if (lane == leader) wcnt[wid][lb] = __popcll(m);
+    }
+    todo &= ~m;
+  }
+  __syncthreads();
+  if (!valid) return;
+  int32_t pre = 0;
+  for (int w = 0; w < wid; ++w) pre += wcnt[w][b];
+  const int32_t v = s.n_ids[i];
+  const int32_t pos = base[b] + s.pblk[(int64_t)b * a.nblk_cap + blockIdx.x] + pre + rank_w;
+  s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
+  if (b < a.P) s.parts[pos] = v;
+  else s.pcached[pos - base[a.P]] = a.cache_map[v];  // nid2cachenid (:1256)
+}
+
+// ----------------------------------------------------------------------------------------------
 // export: widen the slot's int32 arrays into the caller's int64 tensors
 // ----------------------------------------------------------------------------------------------
 struct ExportSegs {
   int32_t n;
-  const int32_t* src[2 * SPP_MAX_HOPS + 1];
-  int64_t* dst[2 * SPP_MAX_HOPS + 1];
-  int64_t start[2 * SPP_MAX_HOPS + 2];
+  const int32_t* src[2 * SPP_MAX_HOPS + 4];
+  int64_t* dst[2 * SPP_MAX_HOPS + 4];
+  int64_t start[2 * SPP_MAX_HOPS + 5];
 };
 
 __device__ __forceinline__ void export_body(const ExportSegs& g, int64_t vblock, int64_t nvblocks) {
@@ -753,6 +861,7 @@ struct spp_sampler {
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
   int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
+  PartDev part{};                    // ownership bucketing (part.P == 0: off)
 };
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -777,6 +886,20 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   SPP_REQUIRE(cfg->num_nodes > 0 && cfg->num_nodes < (1ll << 31), "spp_sampler_create: num_nodes %lld must be < 2^31",
               (long long)cfg->num_nodes);
   SPP_REQUIRE(cfg->max_batch > 0 && cfg->num_slots > 0, "spp_sampler_create: max_batch and num_slots must be > 0");
+  const spp_partition_cfg& pc = cfg->part;
+  SPP_REQUIRE(pc.num_parts >= 0 && pc.num_parts <= SPP_MAX_PARTS, "spp_sampler_create: num_parts %d not in [0,%d]",
+              pc.num_parts, SPP_MAX_PARTS);
+  if (pc.num_parts > 0) {
+    SPP_REQUIRE(pc.rank >= 0 && pc.rank < pc.num_parts, "spp_sampler_create: rank %d out of [0,%d)", pc.rank,
+                pc.num_parts);
+    SPP_REQUIRE(!pc.use_cache || (pc.cache_map_dev && pc.cache_map_len > 0),
+                "spp_sampler_create: use_cache without a cache map");
+    for (int m = 0; m < pc.num_parts; ++m)
+      SPP_REQUIRE(pc.offsets[m] <= pc.offsets[m + 1], "spp_sampler_create: partition offsets must be non-decreasing");
+    SPP_REQUIRE(pc.offsets[0] <= 0 && pc.offsets[pc.num_parts] >= cfg->num_nodes,
+                "spp_sampler_create: partition offsets [%lld,%lld) do not cover the %lld nodes",
+                (long long)pc.offsets[0], (long long)pc.offsets[pc.num_parts], (long long)cfg->num_nodes);
+  }
   int ndev = spp_device_count();
   SPP_REQUIRE(ndev > 0, "spp_sampler_create: no HIP device available (the on-GPU sampler has no CPU fallback)");
   SPP_HIP_TRY(hipSetDevice(cfg->device));
@@ -823,6 +946,16 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
   const int64_t nblk_max = std::max(ceil_div(tmax, kNT), ceil_div(etmp, kNT)) + 1;
   const int nslots = cfg->num_slots;
+  if (pc.num_parts > 0) {
+    s->part.P = pc.num_parts;
+    s->part.rank = pc.rank;
+    s->part.use_cache = pc.use_cache ? 1 : 0;
+    s->part.cache_map = pc.cache_map_dev;
+    s->part.cache_len = pc.cache_map_len;
+    s->part.off.n = pc.num_parts + 1;
+    for (int m = 0; m <= pc.num_parts; ++m) s->part.off.v[m] = pc.offsets[m];
+    s->part.nblk_cap = (int32_t)ceil_div(ucap, kNT);
+  }
 
   s->slots.resize(nslots);
   spp_status rc = SPP_OK;
@@ -869,6 +1002,13 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
       A(p.out_col[h], int32_t, s->ecap[h]);
       sl.ecap_dyn[h] = s->ecap[h];
+    }
+    if (s->part.P > 0) {
+      A(p.parts, int32_t, ucap);
+      A(p.pcached, int32_t, ucap);
+      A(p.pperm, int32_t, ucap);
+      A(p.pbucket, uint8_t, ucap);
+      A(p.pblk, int32_t, (int64_t)(s->part.P + 1) * s->part.nblk_cap);
     }
 #undef A
     p.kcount = s->counts + (size_t)i * (2 * nb + 1);
@@ -1108,6 +1248,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       }
     }
   }
+  if (s->part.P > 0) {
+    const unsigned gu = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[H], kNT));
+    hipLaunchKernelGGL(k_gpart_hist, dim3(gu, gy), dim3(kNT), 0, st, s->d_slots, first_slot, H, s->part);
+    hipLaunchKernelGGL(k_gpart_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, H, s->part);
+    hipLaunchKernelGGL(k_gpart_scatter, dim3(gu, gy), dim3(kNT), 0, st, s->d_slots, first_slot, H, s->part);
+  }
   SPP_HIP_TRY(hipGetLastError());
   SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState) * (size_t)n, hipMemcpyDeviceToHost, st));
   SPP_HIP_TRY(hipEventRecord(lead.done, st));
@@ -1150,6 +1296,13 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
       const int h = H - 1 - k;
       add(sl.p.out_rowptr[h], mfg->rowptr[k], (int64_t)hs->cnt[h] + 1);
       add(sl.p.out_col[h], mfg->col[k], hs->E[h]);
+    }
+    if (s->part.P > 0) {
+      int64_t owned = 0;
+      for (int m = 0; m < s->part.P; ++m) owned += hs->pcnt[m];
+      add(sl.p.parts, mfg->parts, owned);
+      add(sl.p.pcached, mfg->cached, hs->pcnt[s->part.P]);
+      add(sl.p.pperm, mfg->perm, U);
     }
   }
   a.segs.n = n;
@@ -1215,6 +1368,7 @@ static void fill_counts(const spp_sampler* s, const SlotState* hs, spp_mfg_count
     out->S[k] = hs->cnt[h + 1];
     out->E[k] = hs->E[h];
   }
+  for (int m = 0; m < SPP_MAX_PARTS + 2; ++m) out->part_counts[m] = (m < s->part.P + 2 && s->part.P > 0) ? hs->pcnt[m] : 0;
 }
 
 extern "C" spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_counts* out) {
@@ -1260,6 +1414,16 @@ extern "C" spp_status spp_sampler_export(spp_sampler* s, int32_t slot, const spp
     const int h = H - 1 - k;
     add(sl.p.out_rowptr[h], out->rowptr[k], (int64_t)hs->cnt[h] + 1);
     add(sl.p.out_col[h], out->col[k], hs->E[h]);
+  }
+  {
+    const int64_t U = hs->cnt[H];
+    if (s->part.P > 0) {
+      int64_t owned = 0;
+      for (int m = 0; m < s->part.P; ++m) owned += hs->pcnt[m];
+      add(sl.p.parts, out->parts, owned);
+      add(sl.p.pcached, out->cached, hs->pcnt[s->part.P]);
+      add(sl.p.pperm, out->perm, U);
+    }
   }
   g.n = n;
   g.start[n] = total;

@@ -191,6 +191,9 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
                 (long long)cfg->exact_num_batches, (long long)cfg->n_idx);
   auto* s = new spp_session();
   s->cfg = *cfg;
+  s->cfg.part = nullptr;  // caller-owned; only read here
+  spp_partition_cfg want{};
+  if (cfg->part) want = *cfg->part;
   build_ranges(*cfg, s->ranges);
   int64_t max_batch = 1;
   for (auto& r : s->ranges) max_batch = std::max<int64_t>(max_batch, r.second - r.first);
@@ -214,8 +217,15 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
               have.num_hops == cfg->num_hops && have.max_batch >= max_batch && have.device == cfg->device &&
               have.replace == 0 && have.num_slots >= 1;
     for (int h = 0; ok && h < cfg->num_hops; ++h) ok = have.sizes[h] == cfg->sizes[h];
+    ok = ok && have.part.num_parts == want.num_parts;
+    if (ok && want.num_parts > 0) {
+      ok = have.part.rank == want.rank && (have.part.use_cache != 0) == (want.use_cache != 0) &&
+           (!want.use_cache ||
+            (have.part.cache_map_dev == want.cache_map_dev && have.part.cache_map_len == want.cache_map_len));
+      for (int m = 0; ok && m <= want.num_parts; ++m) ok = have.part.offsets[m] == want.offsets[m];
+    }
     if (!ok) {
-      set_error("spp_session_create: borrowed sampler is not compatible with this session's graph/fanouts/batch");
+      set_error("spp_session_create: borrowed sampler is not compatible with this session's graph/fanouts/batch/partitioning");
       delete s;
       return SPP_ERR_INVALID;
     }
@@ -234,6 +244,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
     sc.max_batch = max_batch;
     sc.num_slots = G * sets;
     sc.device = cfg->device;
+    sc.part = want;
     rc = spp_sampler_create(&sc, &s->sampler);
     if (rc != SPP_OK) {
       delete s;

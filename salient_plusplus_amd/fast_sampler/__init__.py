@@ -250,11 +250,14 @@ class _SamplerPool:
     _lock = threading.Lock()
 
     @classmethod
-    def acquire(cls, rowptr_d, col_d, sizes, max_batch, slots, device, replace=False):
-        key = (rowptr_d.data_ptr(), col_d.data_ptr(), tuple(sizes), device, bool(replace))
+    def acquire(cls, rowptr_d, col_d, sizes, max_batch, slots, device, replace=False, part=None):
+        """`part`: None or (PartitionCfg, hashable key, tensors to keep alive) -- ownership bucketing
+        fused into the sampling chain (distributed Sessions)."""
+        key = (rowptr_d.data_ptr(), col_d.data_ptr(), tuple(sizes), device, bool(replace),
+               part[1] if part is not None else None)
         with cls._lock:
             lst = cls._pool.setdefault(key, [])
-            for i, (h, mb, ns, keep) in enumerate(lst):
+            for i, (h, mb, ns, keep, _k) in enumerate(lst):
                 if mb >= max_batch and ns >= slots:
                     return lst.pop(i)
         L = _lib()
@@ -266,22 +269,23 @@ class _SamplerPool:
             cfg.sizes[i] = s
         cfg.max_batch, cfg.num_slots, cfg.device = max_batch, slots, device
         cfg.replace = int(bool(replace))
+        if part is not None:
+            cfg.part = part[0]
         h = C.c_void_p()
         nat.check(L.spp_sampler_create(C.byref(cfg), C.byref(h)))
-        return (h, max_batch, slots, (rowptr_d, col_d))
+        return (h, max_batch, slots, (rowptr_d, col_d, part[2] if part is not None else None), key)
 
     @classmethod
-    def release(cls, key_tensors, sizes, device, entry, replace=False):
-        key = (key_tensors[0].data_ptr(), key_tensors[1].data_ptr(), tuple(sizes), device, bool(replace))
+    def release(cls, entry):
         with cls._lock:
-            cls._pool.setdefault(key, []).append(entry)
+            cls._pool.setdefault(entry[4], []).append(entry)
 
     @classmethod
     def clear(cls):
         with cls._lock:
             L = nat.load()
             for lst in cls._pool.values():
-                for (h, _mb, _ns, _keep) in lst:
+                for (h, _mb, _ns, _keep, _key) in lst:
                     L.spp_sampler_destroy(h)
             cls._pool.clear()
 
@@ -344,8 +348,9 @@ class Session:
         nb, max_batch = _host_ranges(n, int(config.batch_size), bool(config.skip_nonfull_batch), force_exact,
                                      int(config.exact_num_batches))
         slots = max(1, min(int(max_items_in_queue), _MAX_SLOTS, max(nb, 1)))
+        self._part = self._partition_cfg() if self._distributed else None
         self._pool_entry = _SamplerPool.acquire(self._rowptr, self._col, self._sizes, max_batch, slots,
-                                                self._dev.index)
+                                                self._dev.index, part=self._part)
 
         cfg = nat.SessionCfg()
         cfg.rowptr_dev, cfg.col_dev = self._rowptr.data_ptr(), self._col.data_ptr()
@@ -362,11 +367,13 @@ class Session:
         cfg.group_size = int(os.environ.get("SPP_GROUP_SIZE", "0"))   # 0 = auto
         cfg.device = self._dev.index
         cfg.sampler = self._pool_entry[0]
+        if self._part is not None:
+            cfg.part = C.pointer(self._part[0])
         h = C.c_void_p()
         try:
             nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
         except Exception:
-            _SamplerPool.release((self._rowptr, self._col), self._sizes, self._dev.index, self._pool_entry)
+            _SamplerPool.release(self._pool_entry)
             self._pool_entry = None
             raise
         self._h = h
@@ -378,7 +385,6 @@ class Session:
             if self._x is not None and self._x.numel() else (None, 0, 0)
         self._y_args = (C.c_void_p(self._y.data_ptr()), self._y.size(0), self._y.size(1) * self._y.element_size()) \
             if self._y is not None and self._y.numel() else (None, 0, 0)
-        self._part_ws = None
         self._slice_result = []
         # remote-frequency statistics (count_remote_frequency, fast_sampler.cpp:1093-1103 / :835-880)
         self._freq = None
@@ -386,13 +392,37 @@ class Session:
         self.remote_vertices_ordered_by_freq = torch.empty(0, dtype=torch.int64)
         self._freq_reduced = False
 
+    def _partition_cfg(self):
+        """(PartitionCfg, key, keep-alive): the ownership bucketing of the worker distributed branch
+        (fast_sampler.cpp:1017-1272), run inside the native sampling chain."""
+        cfg = self.config
+        pb = cfg.partition_book
+        if pb is None:
+            raise RuntimeError("Config.distributed needs a partition_book")
+        P, rank = int(pb.world_size), int(pb.rank)
+        if P > nat.SPP_MAX_PARTS:
+            raise RuntimeError(f"at most {nat.SPP_MAX_PARTS} partitions are supported, got {P}")
+        offs = [int(v) for v in pb._offsets_host().tolist()]
+        pc = nat.PartitionCfg()
+        pc.num_parts, pc.rank = P, rank
+        for i, v in enumerate(offs):
+            pc.offsets[i] = v
+        use_cache = bool(cfg.use_cache)
+        cmap = cfg.cache.device_map() if use_cache else None
+        pc.use_cache = int(use_cache)
+        pc.cache_map_dev = cmap.data_ptr() if cmap is not None else None
+        pc.cache_map_len = cmap.numel() if cmap is not None else 0
+        key = (P, rank, tuple(offs), use_cache, cmap.data_ptr() if cmap is not None else 0,
+               cmap.numel() if cmap is not None else 0)
+        return (pc, key, cmap)
+
     # ---- lifetime ----
     def close(self):
         if getattr(self, "_h", None) is not None:
             self._L.spp_session_destroy(self._h)
             self._h = None
         if getattr(self, "_pool_entry", None) is not None:
-            _SamplerPool.release((self._rowptr, self._col), self._sizes, self._dev.index, self._pool_entry)
+            _SamplerPool.release(self._pool_entry)
             self._pool_entry = None
 
     def __del__(self):
@@ -438,16 +468,39 @@ class Session:
         nat.check(rc)
         return rc == 1
 
-    def _alloc_mfg(self, counts, want_n_id=True):
+    def _alloc_mfg(self, counts, want_n_id=True, num_parts=0):
         """One int64 arena per batch for n_id and every hop's rowptr/col (a single allocator call
-        instead of 2*hops+1), handed out as views; `e_id` is the shared empty tensor."""
+        instead of 2*hops+1), handed out as views; `e_id` is the shared empty tensor.  With
+        num_parts = P > 0 the arena also holds the ownership buckets; then returns
+        (out, n_id, adjs, (partition_nids, cached_nids, perm))."""
         H = counts.num_hops
         U = int(counts.num_nodes) if want_n_id else 0
         Ts = [int(counts.T[k]) for k in range(H)]
         Es = [int(counts.E[k]) for k in range(H)]
-        arena = torch.empty(U + sum(Ts) + H + sum(Es), dtype=torch.int64, device=self._dev)
+        P = num_parts
+        pc = [int(counts.part_counts[m]) for m in range(P + 1)] if P else []
+        owned = sum(pc[:P]) if P else 0
+        n_part = (owned + pc[P] + int(counts.num_nodes)) if P else 0
+        n_mfg = U + sum(Ts) + H + sum(Es)
+        arena = torch.empty(n_mfg + n_part, dtype=torch.int64, device=self._dev)
         base = arena.data_ptr()
         out = nat.MfgOut()
+        buckets = None
+        if P:
+            o = n_mfg
+            bounds = [o]
+            for m in range(P):
+                bounds.append(bounds[-1] + pc[m])
+            nids = [arena[bounds[m]:bounds[m + 1]] for m in range(P)]
+            flat = arena[bounds[0]:bounds[P]]
+            out.parts = (base + 8 * o) if owned else None
+            o += owned
+            cached = arena[o:o + pc[P]]
+            out.cached = (base + 8 * o) if pc[P] else None
+            o += pc[P]
+            perm = arena[o:o + int(counts.num_nodes)]
+            out.perm = (base + 8 * o) if int(counts.num_nodes) else None
+            buckets = (nids, cached, perm, flat)
         n_id = None
         off = 0
         if want_n_id:
@@ -464,6 +517,8 @@ class Session:
             out.col[k] = (base + 8 * off) if Es[k] else None
             off += Es[k]
             adjs.append((rp, cl, e_id, (Ts[k], int(counts.S[k]))))
+        if P:
+            return out, n_id, adjs, buckets
         return out, n_id, adjs
 
     def blocking_get_batch(self):
@@ -504,37 +559,19 @@ class Session:
         cfg = self.config
         pb = cfg.partition_book
         P, rank = int(pb.world_size), int(pb.rank)
-        out, n_id, adjs = self._alloc_mfg(c)
+        use_cache = bool(cfg.use_cache)
+        # the ownership buckets were built by the sampling chain; their sizes came with the counts
+        out, n_id, adjs, (nids, cached, perm, flat) = self._alloc_mfg(c, num_parts=P)
         y = None
         if self._y is not None:
             y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
         self._export(out, None, y)
-        U = int(c.num_nodes)
-        L = self._L
-        offs = pb._offsets_host()
-        use_cache = bool(cfg.use_cache)
-        cmap = cfg.cache.device_map() if use_cache else None
-        parts = torch.empty(U, dtype=torch.int64, device=self._dev)
-        cached = torch.empty(U, dtype=torch.int64, device=self._dev)
-        perm = torch.empty(U, dtype=torch.int64, device=self._dev)
-        counts = torch.empty(P + 2, dtype=torch.int64, device=self._dev)
-        need = int(L.spp_partition_workspace_bytes(max(U, 1)))
-        if self._part_ws is None or self._part_ws.numel() < need:
-            self._part_ws = torch.empty(need, dtype=torch.uint8, device=self._dev)
-        x_rows = self._x.size(0) if self._x is not None else 0
-        nat.check(L.spp_partition_batch(_ptr(n_id), U, C.c_void_p(offs.data_ptr()), P, rank, int(use_cache),
-                                        _ptr(cmap), cmap.numel() if cmap is not None else 0, x_rows,
-                                        _ptr(parts), _ptr(cached), _ptr(perm), C.c_void_p(counts.data_ptr()),
-                                        None, C.c_void_p(self._part_ws.data_ptr()), self._part_ws.numel(),
-                                        _stream_ptr()))
-        cnt = counts.cpu().tolist()            # sizes are needed on the host to slice the views
         b = ProtoDistributedBatch()
-        bounds = [0]
-        for m in range(P):
-            bounds.append(bounds[-1] + int(cnt[m]))
-        b.partition_nids = [parts[bounds[m]:bounds[m + 1]] for m in range(P)]
-        b.cached_nids = cached[:int(cnt[P])]
+        b.partition_nids = nids
+        b.partition_nids_flat = flat
+        b.cached_nids = cached
         b.perm_partition_to_mfg = perm
+        b.partition_counts = [int(c.part_counts[m]) for m in range(P + 1)]
         feat_dim = self._x.size(1) if self._x is not None else 0
         feat_dtype = self._x.dtype if self._x is not None else torch.float16
         b.sliced_cpu_features = torch.empty((0, feat_dim), dtype=feat_dtype)   # all local rows are in HBM
@@ -647,7 +684,7 @@ def _sample_once(rowptr, col, idx, sizes, replace=False):
         nat.check(L.spp_sampler_export(h, 0, C.byref(out), st))
         torch.cuda.current_stream().synchronize()
     finally:
-        _SamplerPool.release((rowptr_d, col_d), sizes, dev.index, entry, replace)
+        _SamplerPool.release(entry)
     return n_id, adjs
 
 
