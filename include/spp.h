@@ -255,6 +255,8 @@ typedef struct spp_session_cfg {
   /* Optional ownership bucketing (NULL = off).  With a borrowed sampler it must equal the
    * sampler's own spp_partition_cfg. */
   const spp_partition_cfg* part;
+  /* Optional native feature exchange (NULL = off; needs `part`).  See spp_exchange_cfg below. */
+  const struct spp_exchange_cfg* exchange;
 } spp_session_cfg;
 
 typedef struct spp_batch_desc {
@@ -287,6 +289,46 @@ int64_t spp_session_blocked_us(const spp_session* s);
 int64_t spp_session_blocked_occasions(const spp_session* s);
 /* the sampler owned by the session (for spp_sampler_gather on the current slot etc.) */
 spp_sampler* spp_session_sampler(spp_session* s);
+
+/* ------------------------------------------------------------------------- *
+ * e1-e3  Remote-feature exchange over RCCL/xGMI, native (the DeviceDistributedPrefetcher
+ *        stages of transferers.py:186-372: counts C1 :757, node ids C2 :709, feature rows C3 :521,
+ *        serve K5 :645-658, combine :472-486).  One exchange per GROUP of batches (fewer, larger
+ *        collectives), driven by a session-owned thread one group ahead of the consumer:
+ *          all-gather of the request counts -> grouped send/recv of int32 node ids ->
+ *          row gather out of the local partition -> grouped send/recv of the rows;
+ *        spp_session_export then writes x in MFG order straight from {local partition,
+ *        received rows, VIP cache} in the same launch that delivers the MFG and the labels.
+ *        Every rank must run the same number of batches per epoch (force_exact_num_batches,
+ *        as the reference's distributed mode requires).
+ * ------------------------------------------------------------------------- */
+typedef struct spp_comm spp_comm;
+
+#define SPP_COMM_ID_BYTES 128
+/* rank 0: make the rendezvous token (ncclGetUniqueId); ship it to the other ranks out of band
+ * (e.g. torch.distributed broadcast) */
+spp_status spp_comm_unique_id(void* out_id /* SPP_COMM_ID_BYTES */);
+/* collective over all ranks: ncclCommInitRank on `device`.  librccl.so.1 is resolved at run time
+ * (the copy PyTorch already loaded when there is one). */
+spp_status spp_comm_create(const void* id, int32_t rank, int32_t world, int32_t device, spp_comm** out);
+/* `world` communicators that live in ONE process and copy device-to-device (no RCCL): ranks are
+ * driven by different host threads.  For single-GPU testing of the exchange logic only. */
+spp_status spp_comm_create_local(int32_t world, int32_t device, spp_comm** out /* [world] */);
+void spp_comm_destroy(spp_comm* c);
+int32_t spp_comm_rank(const spp_comm* c);
+int32_t spp_comm_world(const spp_comm* c);
+
+typedef struct spp_exchange_cfg {
+  spp_comm* comm;                  /* rank / world must match spp_partition_cfg                     */
+  const void* x_local_dev;         /* this rank's feature rows [offsets[rank], offsets[rank+1]), HBM */
+  int64_t x_local_rows;
+  int64_t row_bytes;
+  const void* cache_feats_dev;     /* VIP cache rows (row_bytes each); NULL without use_cache        */
+  int64_t cache_rows;
+} spp_exchange_cfg;
+
+/* bytes this rank sent / received through the exchange so far (ids + rows + counts) */
+spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes);
 
 #ifdef __cplusplus
 }

@@ -40,13 +40,18 @@ class MfgOut(C.Structure):
                 ("parts", p), ("cached", p), ("perm", p)]
 
 
+class ExchangeCfg(C.Structure):
+    _fields_ = [("comm", p), ("x_local_dev", p), ("x_local_rows", i64), ("row_bytes", i64),
+                ("cache_feats_dev", p), ("cache_rows", i64)]
+
+
 class SessionCfg(C.Structure):
     _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
                 ("idx_dev", p), ("n_idx", i64), ("batch_size", i64), ("num_hops", i32),
                 ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
                 ("force_exact_num_batches", i32), ("exact_num_batches", i64),
                 ("max_items_in_queue", i32), ("group_size", i32), ("device", i32), ("sampler", p),
-                ("part", C.POINTER(PartitionCfg))]
+                ("part", C.POINTER(PartitionCfg)), ("exchange", C.POINTER(ExchangeCfg))]
 
 
 class BatchDesc(C.Structure):
@@ -90,7 +95,15 @@ SIGNATURES = {
     "spp_session_blocked_us": (i64, [p]),
     "spp_session_blocked_occasions": (i64, [p]),
     "spp_session_sampler": (p, [p]),
+    "spp_comm_unique_id": (C.c_int, [p]),
+    "spp_comm_create": (C.c_int, [p, i32, i32, i32, C.POINTER(p)]),
+    "spp_comm_create_local": (C.c_int, [i32, i32, C.POINTER(p)]),
+    "spp_comm_destroy": (None, [p]),
+    "spp_comm_rank": (i32, [p]),
+    "spp_comm_world": (i32, [p]),
+    "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),
 }
+SPP_COMM_ID_BYTES = 128
 
 _lib = None
 

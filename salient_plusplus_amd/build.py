@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libspp_hip.so")
-SOURCES = ["api.hip", "mt19937.hip", "gather.hip", "sampler.hip", "partition.hip", "session.hip"]
+SOURCES = ["api.hip", "mt19937.hip", "gather.hip", "sampler.hip", "partition.hip", "session.hip", "exchange.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
@@ -24,8 +24,8 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "spp_internal.h"), os.path.join(ROOT, "include", "spp.h"),
-               os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".cuh"))]
+    headers += [os.path.join(ROOT, "include", "spp.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

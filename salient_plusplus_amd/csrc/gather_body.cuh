@@ -56,10 +56,10 @@ static inline GatherGeom gather_geometry(const void* src, const void* dst, int64
 // 490 MB table, sustained): plain loads 63 us, non-temporal loads 88-93 us -- the rows are not
 // really read-once (hub rows repeat across batches and MALL/L2 catch them), so plain is the default;
 // the stores stay non-temporal.
-template <int VEC, typename IdxT, bool kNT = false>
-__device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
-                                                 int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
-                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+// move_rows_body: dst[r,:] = *src_of(r) for r < n; `src_of` maps an output row to its source row.
+template <int VEC, bool kNT, typename SrcFn>
+__device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
+                                               char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
   using V = typename vec_of<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int g = threadIdx.x >> lpr_log2;
@@ -74,8 +74,7 @@ __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, c
     for (int u = 0; u < kGatherUnroll; ++u) {
       const int64_t r = base + (int64_t)u * gpb + g;
       ok[u] = r < n;
-      const int64_t sr = ok[u] ? (int64_t)idx[r] : 0;
-      s[u] = reinterpret_cast<const V*>(src + sr * row_bytes);
+      s[u] = reinterpret_cast<const V*>(src_of(ok[u] ? r : 0));
       d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
     }
     for (int c = l; c < chunks; c += lpr) {
@@ -88,6 +87,15 @@ __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, c
         if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);
     }
   }
+}
+
+template <int VEC, typename IdxT, bool kNT = false>
+__device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
+                                                 int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
+                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+  if (n <= 0) return;
+  move_rows_body<VEC, kNT>([=](int64_t r) { return src + (int64_t)idx[r] * row_bytes; }, n, row_bytes, chunks,
+                           lpr_log2, dst, vblock, nvblocks);
 }
 
 }  // namespace spp

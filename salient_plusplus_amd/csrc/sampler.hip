@@ -793,6 +793,15 @@ struct DeliverArgs {
   char* y_dst;
   int64_t y_rows, y_row_bytes;
   const int32_t* n_ids;
+  // x assembled from {local partition, received rows, cache} instead of one table (native exchange)
+  int32_t asm_on, P, rank, pad;
+  int64_t rank_offset;
+  const char* recv;
+  const char* cache;
+  const int32_t* pperm;
+  const int32_t* pcached;
+  int32_t seg_start[SPP_MAX_PARTS + 2];
+  int64_t recv_base[SPP_MAX_PARTS];
 };
 
 template <int VEC>
@@ -800,8 +809,22 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
   static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
   const int b = blockIdx.x;
   if (b < a.nb_x) {
-    gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
-                                   a.nb_x);
+    if (!a.asm_on) {
+      gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
+                                     a.nb_x);
+    } else {
+      // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes
+      move_rows_body<VEC, false>(
+          [&](int64_t r) -> const char* {
+            const int32_t j = a.pperm[r];
+            int m = 0;
+            while (m < a.P && j >= a.seg_start[m + 1]) ++m;
+            if (m == a.rank) return a.x_src + ((int64_t)a.n_ids[r] - a.rank_offset) * a.x_row_bytes;
+            if (m == a.P) return a.cache + (int64_t)a.pcached[j - a.seg_start[m]] * a.x_row_bytes;
+            return a.recv + (a.recv_base[m] + (j - a.seg_start[m])) * a.x_row_bytes;
+          },
+          a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b, a.nb_x);
+    }
   } else if (b < a.nb_x + a.nb_e) {
     export_body(a.segs, b - a.nb_x, a.nb_e);
   } else {
@@ -1270,7 +1293,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 // row gathers in one launch.  Any of mfg / x / y may be absent.
 spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
                            void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
-                           hipStream_t st) {
+                           const AssembleSrc* asrc, hipStream_t st) {
   SlotHost& sl = s->slots[(size_t)slot];
   if (!sl.sampled || !sl.waited) {
     set_error("spp_session_export: slot %d must be sampled and waited first", slot);
@@ -1310,8 +1333,30 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   a.n_ids = sl.p.n_ids;
   a.nb_e = total > 0 ? (int32_t)std::min<int64_t>(ceil_div(total, kNT), 1024) : 0;
   int vec = 1;
+  if (asrc) {
+    SPP_REQUIRE(s->part.P > 0, "sampler_deliver: feature assembly needs ownership bucketing");
+    x_src = asrc->x_local;
+    a.asm_on = 1;
+    a.P = s->part.P;
+    a.rank = s->part.rank;
+    a.rank_offset = s->part.off.v[s->part.rank];
+    a.recv = asrc->recv;
+    a.cache = asrc->cache;
+    a.pperm = sl.p.pperm;
+    a.pcached = sl.p.pcached;
+    int32_t acc = 0;
+    for (int m = 0; m <= s->part.P; ++m) {
+      a.seg_start[m] = acc;
+      acc += hs->pcnt[m];
+    }
+    a.seg_start[s->part.P + 1] = acc;
+    for (int m = 0; m < s->part.P; ++m) a.recv_base[m] = asrc->recv_base[m];
+    SPP_REQUIRE(hs->pcnt[s->part.P] == 0 || asrc->cache, "sampler_deliver: cache hits without cache rows");
+  }
   if (x_src && x_dst && U > 0 && x_row_bytes > 0) {
-    const GatherGeom gg = gather_geometry(x_src, x_dst, x_row_bytes, U);
+    uintptr_t align_probe = reinterpret_cast<uintptr_t>(x_src);
+    if (asrc) align_probe |= reinterpret_cast<uintptr_t>(asrc->recv) | reinterpret_cast<uintptr_t>(asrc->cache);
+    const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U);
     vec = gg.vec;
     a.x_src = static_cast<const char*>(x_src);
     a.x_dst = static_cast<char*>(x_dst);
@@ -1342,6 +1387,19 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   prof_end(SPP_PROF_GATHER, prof, st);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
+}
+
+void sampler_slot_parts(const spp_sampler* s, int slot, SlotParts* out) {
+  const SlotHost& sl = s->slots[(size_t)slot];
+  out->parts = sl.p.parts;
+  out->pcnt = sl.host_state->pcnt;
+  out->num_nodes = sl.host_state->cnt[s->cfg.num_hops];
+  out->error = sl.host_state->error;
+}
+
+hipEvent_t sampler_slot_event(const spp_sampler* s, int slot) {
+  const SlotHost& sl = s->slots[(size_t)slot];
+  return sl.sampled ? sl.wait_on : nullptr;
 }
 
 }  // namespace spp

@@ -24,10 +24,34 @@ spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, co
 spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
                                 const int64_t* n_seeds, hipStream_t st);
 
+// Where the feature rows of a distributed batch come from (native exchange, session.hip): row r of
+// x is row pperm[r] of the virtual concatenation [owner 0 | ... | owner P-1 | cache hits]; the
+// rank-th segment is read from x_local, the cache segment from `cache`, segment m from
+// recv + recv_base[m] rows (rows received from peer m for THIS batch).
+struct AssembleSrc {
+  const char* x_local;
+  const char* recv;
+  const char* cache;
+  int64_t recv_base[SPP_MAX_PARTS];
+};
+
 // Fused delivery of the waited batch in `slot` to caller buffers in one launch on `st`:
-// MFG widening (mfg may be NULL), x = x_src[n_id,:], y = y_src[n_id[:y_rows],:].
+// MFG widening (mfg may be NULL), x = x_src[n_id,:] (or, with `asrc`, assembled from the local
+// partition / received rows / cache), y = y_src[n_id[:y_rows],:].
 spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
                            void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
-                           hipStream_t st);
+                           const AssembleSrc* asrc, hipStream_t st);
+
+// Ownership buckets of the batch in `slot` (valid once the group's completion event has been
+// synchronised): device arrays and the host mirror of the bucket sizes.
+struct SlotParts {
+  const int32_t* parts;    // node ids grouped by owner (device)
+  const int32_t* pcnt;     // host: [P+2] bucket sizes
+  int32_t num_nodes;
+  int32_t error;
+};
+void sampler_slot_parts(const spp_sampler* s, int slot, SlotParts* out);
+// completion event of the group `slot` belongs to (NULL when nothing was sampled into it)
+hipEvent_t sampler_slot_event(const spp_sampler* s, int slot);
 
 }  // namespace spp

@@ -17,8 +17,19 @@
 // of the same stream, into the idle half of a per-slot ping-pong buffer, so the serial generator
 // never delays a sampling chain.  When the last batch of a group has been exported, its slot-set immediately
 // starts the next pending group (ordered after the consumer's copies by events).
+//
+// Native feature exchange (distributed mode, spp_exchange_cfg).  A second session thread follows the
+// launcher one stage behind: as soon as a group's chain has completed it reads the group's bucket
+// sizes from the pinned state mirror and runs ONE exchange for the whole group on a stream of its
+// own -- all-gather of the request counts (C1, transferers.py:757), grouped send/recv of the
+// int32 node ids straight out of the slots (C2, :709), one gather of the requested rows out of the
+// local partition (K5, :645-658), grouped send/recv of the rows (C3, :521).  The only host
+// synchronisation is the one read of the gathered counts per group, off the consumer thread.
+// spp_session_export orders the consumer's stream after the group's rows and assembles x in MFG
+// order inside the delivery launch (sampler.hip k_deliver).
 #include "spp_internal.h"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -27,9 +38,46 @@
 #include <utility>
 #include <vector>
 
+#include "exchange_internal.h"
+#include "gather_body.cuh"
 #include "sampler_internal.h"
 
 using namespace spp;
+
+namespace spp {
+
+// serve (transferers.py:645-658): send_rows[j,:] = x_local[ids[j] - rank_offset,:]
+template <int VEC>
+__global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __restrict__ x_local, int64_t x_rows,
+                                                               const int32_t* __restrict__ ids, int64_t n,
+                                                               int64_t rank_offset, int64_t row_bytes, int chunks,
+                                                               int lpr_log2, char* __restrict__ out) {
+  move_rows_body<VEC, false>(
+      [=](int64_t j) -> const char* {
+        int64_t r = (int64_t)ids[j] - rank_offset;
+        r = r < 0 ? 0 : (r >= x_rows ? x_rows - 1 : r);  // a peer only asks for rows this rank owns
+        return x_local + r * row_bytes;
+      },
+      n, row_bytes, chunks, lpr_log2, out, blockIdx.x, gridDim.x);
+}
+
+}  // namespace spp
+
+// exchange buffers of one slot-set
+struct XSet {
+  int64_t* cnt_dev = nullptr;   // [G*P] this rank's request counts, then [world*G*P] everybody's
+  int64_t* cnt_host = nullptr;  // pinned mirror, same layout
+  int32_t* recv_ids = nullptr;  // node ids the peers request from this rank (peer-major, then batch)
+  int64_t recv_ids_cap = 0;
+  char* send_rows = nullptr;    // their rows, same order
+  int64_t send_rows_cap = 0;    // rows
+  char* recv_rows = nullptr;    // rows received for this rank's batches (batch-major, then peer)
+  int64_t recv_rows_cap = 0;    // rows
+  hipEvent_t cnt_ready = nullptr;
+  hipEvent_t rows_done = nullptr;
+  bool rows_recorded = false;
+  int64_t recv_base[kMaxGroup][SPP_MAX_PARTS];
+};
 
 struct spp_session {
   spp_session_cfg cfg{};
@@ -57,6 +105,19 @@ struct spp_session {
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
   int64_t blocked_us = 0;
   int64_t blocked_occasions = 0;
+  // native exchange (off when tr == nullptr)
+  Transport* tr = nullptr;
+  spp_exchange_cfg xcfg{};
+  int P = 0, rank = 0;
+  int64_t rank_offset = 0;
+  hipStream_t comm_stream = nullptr;
+  std::thread exchanger;
+  int64_t exchange_launched = 0;         // groups whose exchange was enqueued (guarded by mu)
+  spp_status exchange_rc = SPP_OK;
+  std::string exchange_err;
+  std::vector<XSet> xsets;
+  std::vector<void*> retired;            // outgrown buffers, released at destroy
+  std::atomic<int64_t> sent_bytes{0}, recv_bytes{0};
 };
 
 // fast_sampler.cpp:587-627
@@ -133,6 +194,8 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
       s->export_recorded[slot] = 0;
     }
   }
+  // ... and the previous exchange out of these slots (its sends read the slots' id lists)
+  if (s->tr && s->xsets[(size_t)set].rows_recorded) SPP_HIP_TRY(hipStreamWaitEvent(st, s->xsets[(size_t)set].rows_done, 0));
   SPP_TRY(sampler_launch_chain(s->sampler, set * s->G, n, buf, seeds, n_seeds, st));
   if (g + s->num_sets < s->num_groups) SPP_TRY(launch_group_rng(s, g + s->num_sets));
   return SPP_OK;
@@ -180,6 +243,206 @@ static spp_status wait_group_launched(spp_session* s, int64_t g) {
   return s->launch_rc;
 }
 
+// ---- native exchange -----------------------------------------------------------------------------
+static spp_status grow(spp_session* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes) {
+  if (need <= *cap) return SPP_OK;
+  const int64_t ncap = std::max(need + need / 4, *cap * 2);
+  void* v = nullptr;
+  SPP_HIP_TRY(hipMalloc(&v, (size_t)(ncap * unit_bytes)));
+  if (*buf) s->retired.push_back(*buf);  // may still be read by kernels in flight
+  *buf = v;
+  *cap = ncap;
+  return SPP_OK;
+}
+
+static spp_status launch_serve(spp_session* s, const int32_t* ids, int64_t n, char* out, hipStream_t st) {
+  if (n <= 0) return SPP_OK;
+  const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n);
+  const char* x = static_cast<const char*>(s->xcfg.x_local_dev);
+#define SPP_SERVE(V)                                                                                              \
+  hipLaunchKernelGGL(k_serve_rows<V>, dim3((unsigned)gg.grid), dim3(kGatherThreads), 0, st, x, s->xcfg.x_local_rows, \
+                     ids, n, s->rank_offset, s->xcfg.row_bytes, gg.chunks, gg.lpr_log2, out)
+  switch (gg.vec) {
+    case 16: SPP_SERVE(16); break;
+    case 8: SPP_SERVE(8); break;
+    case 4: SPP_SERVE(4); break;
+    case 2: SPP_SERVE(2); break;
+    default: SPP_SERVE(1); break;
+  }
+#undef SPP_SERVE
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+// one exchange for all batches of group g (its chain has been launched)
+static spp_status exchange_group(spp_session* s, int64_t g) {
+  const int set = (int)(g % s->num_sets);
+  const int n = group_len(s, g);
+  const int P = s->P, R = s->rank, G = s->G;
+  XSet& x = s->xsets[(size_t)set];
+  hipStream_t st = s->comm_stream;
+  Transport* tr = s->tr;
+  const int64_t rb = s->xcfg.row_bytes;
+
+  hipEvent_t chain_done = sampler_slot_event(s->sampler, set * G);
+  SPP_REQUIRE(chain_done, "exchange: group %lld has no sampling chain in flight", (long long)g);
+  SPP_HIP_TRY(hipEventSynchronize(chain_done));
+  SlotParts sp[kMaxGroup];
+  for (int i = 0; i < n; ++i) {
+    sampler_slot_parts(s->sampler, set * G + i, &sp[i]);
+    if (sp[i].error) {
+      set_error("spp_sampler: batch exceeded the slot workspace (error mask %d)", sp[i].error);
+      return SPP_ERR_CAPACITY;
+    }
+  }
+  // C1: what this rank requests from every owner, per batch; everybody learns everybody's requests
+  const size_t cnt_elems = (size_t)G * (size_t)P;
+  for (size_t k = 0; k < cnt_elems; ++k) x.cnt_host[k] = 0;
+  for (int i = 0; i < n; ++i)
+    for (int m = 0; m < P; ++m)
+      if (m != R) x.cnt_host[(size_t)i * P + m] = sp[i].pcnt[m];
+  int64_t* all_dev = x.cnt_dev + cnt_elems;
+  int64_t* all_host = x.cnt_host + cnt_elems;
+  SPP_HIP_TRY(hipMemcpyAsync(x.cnt_dev, x.cnt_host, cnt_elems * 8, hipMemcpyHostToDevice, st));
+  SPP_TRY(tr->all_gather(x.cnt_dev, all_dev, cnt_elems * 8, st));
+  SPP_HIP_TRY(hipMemcpyAsync(all_host, all_dev, cnt_elems * 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  SPP_HIP_TRY(hipEventRecord(x.cnt_ready, st));
+  SPP_HIP_TRY(hipEventSynchronize(x.cnt_ready));
+  auto req = [&](int m, int i) { return all_host[((size_t)m * G + i) * P + R]; };  // rows peer m wants from me
+
+  // layouts: requests served by this rank are peer-major (one contiguous span per peer and batch);
+  // rows coming back are batch-major so that a batch's assembly reads one region
+  int64_t off_req[SPP_MAX_PARTS][kMaxGroup];
+  int64_t total_req = 0, total_in = 0;
+  for (int m = 0; m < P; ++m)
+    for (int i = 0; i < n; ++i) {
+      off_req[m][i] = total_req;
+      if (m != R) total_req += req(m, i);
+    }
+  for (int i = 0; i < n; ++i)
+    for (int m = 0; m < P; ++m) {
+      x.recv_base[i][m] = total_in;
+      if (m != R) total_in += sp[i].pcnt[m];
+    }
+  SPP_TRY(grow(s, (void**)&x.recv_ids, &x.recv_ids_cap, total_req, 4));
+  SPP_TRY(grow(s, (void**)&x.send_rows, &x.send_rows_cap, total_req, rb));
+  SPP_TRY(grow(s, (void**)&x.recv_rows, &x.recv_rows_cap, total_in, rb));
+
+  // C2: node ids, int32, sent straight out of the slots' bucket lists
+  SPP_TRY(tr->group_begin());
+  for (int m = 0; m < P; ++m) {
+    if (m == R) continue;
+    for (int i = 0; i < n; ++i) {
+      int64_t base = 0;
+      for (int q = 0; q < m; ++q) base += sp[i].pcnt[q];
+      const int64_t c = sp[i].pcnt[m];
+      if (c > 0) SPP_TRY(tr->send(sp[i].parts + base, (size_t)c * 4, m, st));
+      const int64_t r = req(m, i);
+      if (r > 0) SPP_TRY(tr->recv(x.recv_ids + off_req[m][i], (size_t)r * 4, m, st));
+    }
+  }
+  SPP_TRY(tr->group_end(st));
+  // K5: one gather of every requested row
+  SPP_TRY(launch_serve(s, x.recv_ids, total_req, x.send_rows, st));
+  // C3: the rows
+  SPP_TRY(tr->group_begin());
+  for (int m = 0; m < P; ++m) {
+    if (m == R) continue;
+    for (int i = 0; i < n; ++i) {
+      const int64_t r = req(m, i);
+      if (r > 0) SPP_TRY(tr->send(x.send_rows + off_req[m][i] * rb, (size_t)(r * rb), m, st));
+      const int64_t c = sp[i].pcnt[m];
+      if (c > 0) SPP_TRY(tr->recv(x.recv_rows + x.recv_base[i][m] * rb, (size_t)(c * rb), m, st));
+    }
+  }
+  SPP_TRY(tr->group_end(st));
+  SPP_HIP_TRY(hipEventRecord(x.rows_done, st));
+  x.rows_recorded = true;
+  s->sent_bytes += total_req * rb + total_in * 4 + (int64_t)cnt_elems * 8;
+  s->recv_bytes += total_in * rb + total_req * 4 + (int64_t)cnt_elems * 8 * P;
+  return SPP_OK;
+}
+
+static void exchanger_main(spp_session* s) {
+  (void)hipSetDevice(s->cfg.device);
+  for (int64_t g = 0; g < s->num_groups; ++g) {
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      s->cv.wait(lk, [s, g] { return s->stop || s->launch_rc != SPP_OK || s->chain_launched > g; });
+      if (s->stop || s->chain_launched <= g) return;
+    }
+    const spp_status rc = exchange_group(s, g);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (rc != SPP_OK) {
+        s->exchange_rc = rc;
+        s->exchange_err = spp_last_error();
+      } else {
+        s->exchange_launched = g + 1;
+      }
+    }
+    s->cv.notify_all();
+    if (rc != SPP_OK) return;
+  }
+}
+
+static spp_status wait_group_exchanged(spp_session* s, int64_t g) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  s->cv.wait(lk, [s, g] { return s->exchange_launched > g || s->exchange_rc != SPP_OK || s->launch_rc != SPP_OK; });
+  if (s->exchange_launched > g) return SPP_OK;
+  if (s->exchange_rc != SPP_OK) {
+    set_error("%s", s->exchange_err.c_str());
+    return s->exchange_rc;
+  }
+  set_error("%s", s->launch_err.c_str());
+  return s->launch_rc;
+}
+
+static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, const spp_partition_cfg& part) {
+  Transport* tr = comm_transport(xc->comm);
+  SPP_REQUIRE(tr, "spp_session_create: exchange without a communicator");
+  SPP_REQUIRE(part.num_parts > 0, "spp_session_create: the native exchange needs spp_partition_cfg");
+  SPP_REQUIRE(tr->world() == part.num_parts && tr->rank() == part.rank,
+              "spp_session_create: communicator is rank %d of %d but the partition book says %d of %d", tr->rank(),
+              tr->world(), part.rank, part.num_parts);
+  SPP_REQUIRE(xc->row_bytes > 0 && (xc->x_local_dev || xc->x_local_rows == 0), "spp_session_create: bad x_local");
+  SPP_REQUIRE(xc->x_local_rows >= part.offsets[part.rank + 1] - part.offsets[part.rank],
+              "spp_session_create: x_local holds %lld rows, the partition owns %lld", (long long)xc->x_local_rows,
+              (long long)(part.offsets[part.rank + 1] - part.offsets[part.rank]));
+  SPP_REQUIRE(!part.use_cache || xc->cache_feats_dev || xc->cache_rows == 0,
+              "spp_session_create: use_cache without cache rows");
+  s->xcfg = *xc;
+  s->P = part.num_parts;
+  s->rank = part.rank;
+  s->rank_offset = part.offsets[part.rank];
+  SPP_HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  s->xsets.resize((size_t)s->num_sets);
+  const size_t cnt_elems = (size_t)s->G * (size_t)s->P;
+  for (auto& x : s->xsets) {
+    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_elems * 8 * (size_t)(s->P + 1)));
+    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_elems * 8 * (size_t)(s->P + 1), hipHostMallocDefault));
+    SPP_HIP_TRY(hipEventCreateWithFlags(&x.cnt_ready, hipEventDisableTiming));
+    SPP_HIP_TRY(hipEventCreateWithFlags(&x.rows_done, hipEventDisableTiming));
+  }
+  s->tr = tr;
+  return SPP_OK;
+}
+
+static void exchange_teardown(spp_session* s) {
+  if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+  for (auto& x : s->xsets) {
+    if (x.cnt_dev) (void)hipFree(x.cnt_dev);
+    if (x.cnt_host) (void)hipHostFree(x.cnt_host);
+    if (x.recv_ids) (void)hipFree(x.recv_ids);
+    if (x.send_rows) (void)hipFree(x.send_rows);
+    if (x.recv_rows) (void)hipFree(x.recv_rows);
+    if (x.cnt_ready) (void)hipEventDestroy(x.cnt_ready);
+    if (x.rows_done) (void)hipEventDestroy(x.rows_done);
+  }
+  for (void* v : s->retired) (void)hipFree(v);
+  if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+}
+
 extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session** out) {
   SPP_REQUIRE(cfg && out, "spp_session_create: NULL argument");
   SPP_REQUIRE(cfg->max_items_in_queue > 0, "max_items_in_queue (%d) must be positive", cfg->max_items_in_queue);
@@ -192,6 +455,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   auto* s = new spp_session();
   s->cfg = *cfg;
   s->cfg.part = nullptr;  // caller-owned; only read here
+  s->cfg.exchange = nullptr;
   spp_partition_cfg want{};
   if (cfg->part) want = *cfg->part;
   build_ranges(*cfg, s->ranges);
@@ -266,8 +530,10 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   s->export_done.assign((size_t)(sets * G), nullptr);
   s->export_recorded.assign((size_t)(sets * G), 0);
   for (auto& e : s->export_done) mk_event(&e);
+  if (rc == SPP_OK && cfg->exchange) rc = exchange_setup(s, cfg->exchange, want);
   if (rc == SPP_OK) {
     s->launcher = std::thread(launcher_main, s);  // primes the pipeline right away
+    if (s->tr) s->exchanger = std::thread(exchanger_main, s);
     if (s->num_groups > 0) rc = wait_group_launched(s, 0);
   }
   if (rc != SPP_OK) {
@@ -288,7 +554,9 @@ extern "C" void spp_session_destroy(spp_session* s) {
     s->cv.notify_all();
     s->launcher.join();
   }
+  if (s->exchanger.joinable()) s->exchanger.join();  // `stop` is set; it leaves after the group in hand
   (void)hipSetDevice(s->cfg.device);
+  exchange_teardown(s);
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
@@ -339,6 +607,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   const auto t0 = std::chrono::steady_clock::now();
   spp_status rc = wait_group_launched(s, g);
   if (rc == SPP_OK) rc = spp_sampler_wait(s->sampler, slot, &out->counts);
+  if (rc == SPP_OK && s->tr) rc = wait_group_exchanged(s, g);
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   if (us > 50) {  // the reference counts only waits that actually spun (fast_sampler.cpp:788-799)
     s->blocked_us += us;
@@ -369,9 +638,30 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   (void)y_rows;
   // one launch: MFG widening, x_s = serial_index(x, n_id) (fast_sampler.cpp:1006) and
   // y_s = serial_index(y, n_id, batch_size) (fast_sampler.cpp:1009)
-  SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
-                          y_out_dev, as_stream(stream)));
+  if (s->tr) {
+    // x comes from the exchange: order the consumer after the group's rows and assemble in place
+    const int64_t g = b / s->G;
+    const XSet& x = s->xsets[(size_t)(g % s->num_sets)];
+    SPP_HIP_TRY(hipStreamWaitEvent(as_stream(stream), x.rows_done, 0));
+    AssembleSrc src{};
+    src.x_local = static_cast<const char*>(s->xcfg.x_local_dev);
+    src.recv = x.recv_rows;
+    src.cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
+    for (int m = 0; m < s->P; ++m) src.recv_base[m] = x.recv_base[b % s->G][m];
+    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, nullptr, s->xcfg.row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
+                            y_out_dev, &src, as_stream(stream)));
+  } else {
+    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
+                            y_out_dev, nullptr, as_stream(stream)));
+  }
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
   s->export_recorded[(size_t)slot] = 1;
   return retire_current(s);
+}
+
+extern "C" spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes) {
+  SPP_REQUIRE(s, "spp_session_exchange_stats: NULL session");
+  if (sent_bytes) *sent_bytes = s->sent_bytes.load();
+  if (recv_bytes) *recv_bytes = s->recv_bytes.load();
+  return SPP_OK;
 }

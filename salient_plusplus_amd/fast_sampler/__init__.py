@@ -27,7 +27,8 @@ import torch
 from .. import _native as nat
 
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
-           "multilayer_sample", "full_sample", "to_row_major", "serial_index"]
+           "multilayer_sample", "full_sample", "to_row_major", "serial_index", "NativeComm", "native_comm",
+           "set_native_comm"]
 
 _MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "16"))
 
@@ -239,6 +240,75 @@ class ProtoDistributedBatch:
         self.idx_range = (0, 0)
         # extras of the GPU path (ignored by reference-style consumers)
         self.n_id = None
+        self.x = None              # native exchange: the batch's features, already assembled in MFG order
+
+
+# --------------------------------------------------------------------------------------------
+# native RCCL communicator of the feature exchange (spp_comm, include/spp.h e1-e3)
+# --------------------------------------------------------------------------------------------
+class NativeComm:
+    """Owns one spp_comm handle."""
+
+    def __init__(self, handle, rank, world):
+        self.handle, self.rank, self.world = handle, int(rank), int(world)
+
+    def close(self):
+        if self.handle is not None:
+            nat.load().spp_comm_destroy(self.handle)
+            self.handle = None
+
+    @staticmethod
+    def local(world: int) -> List["NativeComm"]:
+        """`world` in-process ranks that copy device-to-device (single-GPU testing of the exchange
+        logic; drive each rank from its own thread)."""
+        L = _lib()
+        arr = (C.c_void_p * world)()
+        nat.check(L.spp_comm_create_local(world, _device().index, arr))
+        return [NativeComm(C.c_void_p(arr[m]), m, world) for m in range(world)]
+
+
+_comm_tls = threading.local()
+_comm_auto = {}
+_comm_lock = threading.Lock()
+
+
+def set_native_comm(comm: Optional[NativeComm]):
+    """Pin the communicator distributed Sessions created by THIS thread use (None = automatic)."""
+    _comm_tls.comm = comm
+
+
+def native_comm(group=None) -> Optional[NativeComm]:
+    """The communicator of the native feature exchange, or None when the exchange has to go through
+    torch.distributed (SPP_DIST_TRANSPORT=torch, no NCCL process group, ...).
+
+    The first call is COLLECTIVE over `group`: rank 0's RCCL id is broadcast with torch.distributed
+    and every rank joins with ncclCommInitRank."""
+    pinned = getattr(_comm_tls, "comm", None)
+    if pinned is not None:
+        return pinned
+    if os.environ.get("SPP_DIST_TRANSPORT", "rccl").lower() == "torch":
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        return None
+    key = id(group) if group is not None else 0
+    with _comm_lock:
+        if key in _comm_auto:
+            return _comm_auto[key]
+        L = _lib()
+        dev = _device()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = torch.zeros(nat.SPP_COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            nat.check(L.spp_comm_unique_id(C.c_void_p(buf.data_ptr())))
+        buf = buf.to(dev)
+        dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        token = buf.cpu().contiguous()
+        h = C.c_void_p()
+        nat.check(L.spp_comm_create(C.c_void_p(token.data_ptr()), rank, world, dev.index, C.byref(h)))
+        comm = NativeComm(h, rank, world)
+        _comm_auto[key] = comm
+        return comm
 
 
 # --------------------------------------------------------------------------------------------
@@ -369,6 +439,26 @@ class Session:
         cfg.sampler = self._pool_entry[0]
         if self._part is not None:
             cfg.part = C.pointer(self._part[0])
+        self.native_exchange = False
+        self._cache_feats = None
+        if self._distributed:
+            comm = native_comm()
+            pb = config.partition_book
+            if comm is not None and self._x is not None and \
+                    (comm.world, comm.rank) == (int(pb.world_size), int(pb.rank)):
+                xc = nat.ExchangeCfg()
+                xc.comm = comm.handle
+                xc.x_local_dev, xc.x_local_rows = self._x.data_ptr(), self._x.size(0)
+                xc.row_bytes = self._x.size(1) * self._x.element_size()
+                if bool(config.use_cache):
+                    self._cache_feats = config.cache.device_features()
+                    if self._cache_feats.numel():
+                        if self._cache_feats.dtype != self._x.dtype or self._cache_feats.size(1) != self._x.size(1):
+                            raise RuntimeError("cached_features must match the feature rows in dtype and width")
+                        xc.cache_feats_dev, xc.cache_rows = self._cache_feats.data_ptr(), self._cache_feats.size(0)
+                self._xc = xc
+                cfg.exchange = C.pointer(xc)
+                self.native_exchange = True
         h = C.c_void_p()
         try:
             nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
@@ -560,6 +650,8 @@ class Session:
         pb = cfg.partition_book
         P, rank = int(pb.world_size), int(pb.rank)
         use_cache = bool(cfg.use_cache)
+        if self.native_exchange:
+            return self._native_distributed_batch(d, c, P, rank, use_cache)
         # the ownership buckets were built by the sampling chain; their sizes came with the counts
         out, n_id, adjs, (nids, cached, perm, flat) = self._alloc_mfg(c, num_parts=P)
         y = None
@@ -584,6 +676,47 @@ class Session:
         return b
 
     try_get_batch_distributed = blocking_get_batch_distributed
+
+    def _native_distributed_batch(self, d, c, P, rank, use_cache):
+        """The exchange already ran natively (session.hip): one launch delivers the MFG, the labels
+        and x assembled from {local partition, rows received over RCCL, VIP cache}."""
+        cfg = self.config
+        want_parts = bool(cfg.count_remote_frequency) and not use_cache
+        if want_parts:
+            out, n_id, adjs, (nids, cached, perm, flat) = self._alloc_mfg(c, num_parts=P)
+        else:
+            out, n_id, adjs = self._alloc_mfg(c)
+            nids, cached, perm, flat = [], None, None, None
+        x = torch.empty((c.num_nodes, self._x.size(1)), dtype=self._x.dtype, device=self._dev)
+        y = None
+        if self._y is not None:
+            y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
+        ya = self._y_args if y is not None else (None, 0, 0)
+        nat.check(self._L.spp_session_export(
+            self._h, C.byref(out), None, 0, 0, C.c_void_p(x.data_ptr()) if x.numel() else None,
+            ya[0], ya[1], ya[2], C.c_void_p(y.data_ptr()) if ya[0] is not None and y.numel() else None,
+            C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)))
+        b = ProtoDistributedBatch()
+        b.x = x
+        b.partition_nids = nids
+        b.partition_nids_flat = flat
+        b.cached_nids = cached
+        b.perm_partition_to_mfg = perm
+        b.partition_counts = [int(c.part_counts[m]) for m in range(P + 1)]
+        b.sliced_cpu_features = torch.empty((0, self._x.size(1)), dtype=self._x.dtype)
+        b.sliced_cpu_labels = y if y is not None else torch.zeros(0)
+        b.adjs = adjs
+        b.idx_range = (int(d.start), int(d.stop))
+        b.n_id = n_id
+        if want_parts:
+            self._count_remote(b.partition_nids, rank)
+        return b
+
+    def exchange_bytes(self):
+        """(sent, received) bytes of the native exchange so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        nat.check(self._L.spp_session_exchange_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- host-memory slicing for peers (fast_sampler.cpp:716-775): nothing lives in host memory ----
     def async_slice_tensors(self, ids: List[torch.Tensor], my_rank: int):

@@ -40,6 +40,8 @@ class ProtoDistributedBatch(NamedTuple):
     adjs: List[Adj]
     idx_range: slice
     n_id: Optional[torch.Tensor] = None    # MFG node ids (extra of the GPU path)
+    x: Optional[torch.Tensor] = None       # native exchange: features already assembled in MFG order
+    partition_nids_flat: Optional[torch.Tensor] = None   # cat(partition_nids) when they share one buffer
 
     @classmethod
     def from_fast_sampler(cls, batch):
@@ -52,13 +54,15 @@ class ProtoDistributedBatch(NamedTuple):
                    perm_partition_to_mfg=batch.perm_partition_to_mfg,
                    adjs=[Adj__from_fast_sampler(a) for a in batch.adjs],
                    idx_range=slice(start, stop),
-                   n_id=getattr(batch, "n_id", None))
+                   n_id=getattr(batch, "n_id", None),
+                   x=getattr(batch, "x", None),
+                   partition_nids_flat=getattr(batch, "partition_nids_flat", None))
 
     def record_stream(self, stream):
         for part in self.partition_nids:
             if part.is_cuda:
                 part.record_stream(stream)
-        for t in (self.perm_partition_to_mfg, self.cached_nids, self.n_id):
+        for t in (self.perm_partition_to_mfg, self.cached_nids, self.n_id, self.x):
             if t is not None and t.is_cuda:
                 t.record_stream(stream)
         for adj in self.adjs:

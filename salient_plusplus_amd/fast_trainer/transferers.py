@@ -117,10 +117,16 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.partition_book = cfg.partition_book
         self.cache = cfg.cache
         self.use_cache = bool(cfg.use_cache)
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
-        assert self.world_size == int(self.partition_book.world_size), "partition book / process group mismatch"
-        assert self.rank == int(self.partition_book.rank)
+        # The GPU Session can run the whole exchange natively (RCCL, session.hip): its batches arrive
+        # with x assembled and this iterator only double-buffers them like DevicePrefetcher.
+        self.native = bool(getattr(self.it.session, "native_exchange", False))
+        if self.native:
+            self.rank, self.world_size = int(self.partition_book.rank), int(self.partition_book.world_size)
+        else:
+            self.rank = dist.get_rank(group)
+            self.world_size = dist.get_world_size(group)
+            assert self.world_size == int(self.partition_book.world_size), "partition book / process group mismatch"
+            assert self.rank == int(self.partition_book.rank)
         self.other_ranks = [r for r in range(self.world_size) if r != self.rank]
         self.ops = ops if ops is not None else _HipFeatureOps()
         self.offsets = [int(v) for v in self.partition_book.partition_offsets.tolist()]
@@ -151,7 +157,7 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.NUMBER_OF_SENT_BYTES = 0
         self.ITERATION = 0
         self._exhausted = False
-        depth = 2 if pipeline_on else 0
+        depth = 2 if (pipeline_on and not self.native) else 0
         for _ in range(depth):
             self._advance(produce_output=False)
         self._advance(produce_output=True)
@@ -254,6 +260,20 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.next = [PreparedBatch(x, y, proto.adjs, proto.idx_range)]
 
     def _advance(self, produce_output: bool):
+        if self.native:
+            if not produce_output:
+                return
+            with self.side:
+                runtime_stats_cuda.start_region("sampling2")
+                proto = next(self.it, None)
+                runtime_stats_cuda.end_region("sampling2")
+                if proto is None:
+                    self.next = None
+                    sent, _recv = self.it.session.exchange_bytes()
+                    self.NUMBER_OF_SENT_BYTES = sent
+                else:
+                    self.next = [PreparedBatch(proto.x, proto.sliced_cpu_labels, proto.adjs, proto.idx_range)]
+            return
         with self.side:
             if produce_output:
                 runtime_stats_cuda.start_region("stage_combine_features")

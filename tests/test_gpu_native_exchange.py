@@ -1,0 +1,170 @@
+"""GPU: the native feature exchange of the Session (include/spp.h e1-e3, session.hip) -- counts
+all-gather, int32 id exchange, row serving, row exchange and the fused assembly -- with TWO ranks
+on one GPU.  RCCL refuses two ranks on one device, so the ranks live in one process (one thread
+each) on the in-process transport (spp_comm_create_local); everything above the transport's
+send/recv primitives is the product path.  A world-size-1 RCCL communicator covers the RCCL
+binding itself (dlopen, ncclCommInitRank, all-gather)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [15, 10, 5]
+
+
+def _graph():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "graph_a.npz"))
+    return {k: g[k] for k in g.files}
+
+
+def _rank_cfg(g, rank, P, offsets, use_cache, nb, bs, fs):
+    from salient_plusplus_amd.fast_trainer.samplers import FastSamplerConfig
+    T = torch.from_numpy
+    n = g["rowptr"].shape[0] - 1
+    lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+    x = g["x"]
+    rng = np.random.default_rng(100 + rank)
+    remote = np.setdiff1d(np.arange(n), np.arange(lo, hi))
+    cache = fs.Cache()
+    if use_cache:
+        cv = np.sort(rng.choice(remote, size=250, replace=False)).astype(np.int64)
+        cache = fs.Cache(rank, P, T(cv), T(x[cv].copy()))
+    idx = g["idx"][(len(g["idx"]) * rank) // P:(len(g["idx"]) * (rank + 1)) // P]
+    cut = (hi - lo) // 3
+    cfg = FastSamplerConfig(
+        x_cpu=T(x[lo:hi][cut:].copy()), x_gpu=T(x[lo:hi][:cut].copy()).cuda(), y=T(g["y"]).unsqueeze(-1),
+        rowptr=T(g["rowptr"]), col=T(g["col"]), idx=T(idx), batch_size=bs, sizes=SIZES,
+        skip_nonfull_batch=False, pin_memory=False, distributed=True,
+        partition_book=fs.RangePartitionBook(rank, P, T(np.asarray(offsets, dtype=np.int64))), cache=cache,
+        force_exact_num_batches=True, exact_num_batches=nb, count_remote_frequency=False, use_cache=use_cache)
+    return cfg, idx
+
+
+def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stats):
+    it = None
+    try:
+        from oracle import oracle as orc
+        from salient_plusplus_amd import fast_sampler as fs
+        from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+        from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher
+        torch.cuda.set_device(0)
+        fs.set_native_comm(comms[rank])
+        cfg, idx = _rank_cfg(g, rank, P, offsets, use_cache, nb, bs, fs)
+        ranges = orc.batch_ranges(len(idx), bs, False, True, nb)
+        dev = torch.device("cuda", 0)
+        x = g["x"]
+        for epoch in range(2):          # the second epoch reuses the pooled sampler and grown buffers
+            it = iter(FastSampler(2, slots, cfg))
+            assert it.session.native_exchange
+            pre = DeviceDistributedPrefetcher([dev], it, True)
+            got = 0
+            for (batch,) in pre:
+                start, stop = int(ranges[got][0]), int(ranges[got][1])
+                m = orc.sample_batch(g["rowptr"], g["col"], idx, start, stop, SIZES)
+                assert batch.x.is_cuda
+                np.testing.assert_array_equal(batch.x.cpu().numpy().view(np.uint16), x[m.n_id].view(np.uint16))
+                np.testing.assert_array_equal(batch.y.cpu().numpy().reshape(-1), g["y"][m.n_id[:stop - start]])
+                for adj, hop in zip(batch.adjs, m.hops):
+                    rp, cl, _ = adj.adj_t.csr()
+                    np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
+                    np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+                got += 1
+            assert got == nb
+            stats[rank] = pre.NUMBER_OF_SENT_BYTES
+            it.session.close()
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        errors.append(f"rank {rank}: {e}\n{traceback.format_exc()}")
+        if it is not None:
+            it.session.close()
+        comms[rank].close()     # wakes the peers out of the rendezvous
+    finally:
+        from salient_plusplus_amd import fast_sampler as fs
+        fs.set_native_comm(None)
+
+
+@pytest.mark.parametrize("P,use_cache,nb,bs,slots", [
+    (2, False, 3, 32, 6),       # one group holds all batches
+    (2, True, 7, 16, 4),        # several groups, 2-slot sets, ragged last group, VIP cache
+    (3, True, 5, 24, 16),       # three ranks
+])
+def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
+    from salient_plusplus_amd import fast_sampler as fs
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    offsets = [0, 1400, n] if P == 2 else [0, 900, 2100, n]
+    comms = fs.NativeComm.local(P)
+    errors, stats = [], {}
+    ts = [threading.Thread(target=_run_rank, args=(r, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stats))
+          for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    hung = [t for t in ts if t.is_alive()]
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not hung, "rank thread hung"
+    assert all(stats[r] > 0 for r in range(P))     # rows really travelled
+
+
+def test_rccl_world1_comm_and_session():
+    """ncclCommInitRank through the late-bound RCCL, then a distributed Session on it (no peers:
+    every row is local, but the counts all-gather and the assembly launch run)."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    L = nat.load()
+    token = (C.c_uint8 * nat.SPP_COMM_ID_BYTES)()
+    nat.check(L.spp_comm_unique_id(token))
+    h = C.c_void_p()
+    nat.check(L.spp_comm_create(token, 0, 1, 0, C.byref(h)))
+    assert L.spp_comm_rank(h) == 0 and L.spp_comm_world(h) == 1
+    comm = fs.NativeComm(h, 0, 1)
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    try:
+        fs.set_native_comm(comm)
+        cfg, idx = _rank_cfg(g, 0, 1, [0, n], False, 4, 32, fs)
+        ranges = orc.batch_ranges(len(idx), 32, False, True, 4)
+        it = iter(FastSampler(2, 4, cfg))
+        assert it.session.native_exchange
+        for k, proto in enumerate(it):
+            m = orc.sample_batch(g["rowptr"], g["col"], idx, int(ranges[k][0]), int(ranges[k][1]), SIZES)
+            np.testing.assert_array_equal(proto.x.cpu().numpy().view(np.uint16), g["x"][m.n_id].view(np.uint16))
+            np.testing.assert_array_equal(proto.n_id.cpu().numpy(), m.n_id)
+        it.session.close()
+    finally:
+        fs.set_native_comm(None)
+        comm.close()
+
+
+def test_exchange_rejects_mismatched_communicator():
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    comms = fs.NativeComm.local(2)
+    try:
+        fs.set_native_comm(comms[0])
+        # partition book says rank 1 of 2, the communicator is rank 0: the Session must not pick it up
+        cfg, _ = _rank_cfg(g, 1, 2, [0, 1400, n], False, 2, 32, fs)
+        it = iter(FastSampler(2, 4, cfg))
+        assert not it.session.native_exchange
+        it.session.close()
+    finally:
+        fs.set_native_comm(None)
+        for c in comms:
+            c.close()
