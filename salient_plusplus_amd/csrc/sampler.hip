@@ -755,6 +755,26 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
   else s.pcached[pos - base[a.P]] = a.cache_map[v];  // nid2cachenid (:1256)
 }
 
+// ids requested from the peers, regrouped peer-major across the batches of a group (one send per
+// peer instead of one per peer and batch)
+__global__ __launch_bounds__(kNT) void k_pack_remote_ids(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+                                                         int32_t P, int32_t rank,
+                                                         const int64_t* __restrict__ pack_base,
+                                                         int32_t* __restrict__ out) {
+  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotState* st = s.st;
+  if (st->error) return;
+  const int32_t j = blockIdx.x * kNT + threadIdx.x;
+  int32_t seg = 0, m = 0;
+  for (; m < P; ++m) {
+    const int32_t c = st->pcnt[m];
+    if (j < seg + c) break;
+    seg += c;
+  }
+  if (m >= P || m == rank) return;
+  out[pack_base[(int64_t)blockIdx.y * P + m] + (j - seg)] = s.parts[j];
+}
+
 // ----------------------------------------------------------------------------------------------
 // export: widen the slot's int32 arrays into the caller's int64 tensors
 // ----------------------------------------------------------------------------------------------
@@ -1395,6 +1415,17 @@ void sampler_slot_parts(const spp_sampler* s, int slot, SlotParts* out) {
   out->pcnt = sl.host_state->pcnt;
   out->num_nodes = sl.host_state->cnt[s->cfg.num_hops];
   out->error = sl.host_state->error;
+}
+
+spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const int64_t* pack_base_dev,
+                                   int32_t* out_dev, hipStream_t st) {
+  SPP_REQUIRE(s->part.P > 0, "sampler_pack_remote_ids: no ownership bucketing");
+  SPP_REQUIRE(n >= 1 && first_slot >= 0 && first_slot + n <= (int)s->slots.size(), "sampler_pack_remote_ids: bad slots");
+  const unsigned gx = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[s->cfg.num_hops], kNT));
+  hipLaunchKernelGGL(k_pack_remote_ids, dim3(gx, (unsigned)n), dim3(kNT), 0, st, s->d_slots, first_slot, s->part.P,
+                     s->part.rank, pack_base_dev, out_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
 }
 
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot) {

@@ -51,6 +51,11 @@ struct SlotParts {
   int32_t error;
 };
 void sampler_slot_parts(const spp_sampler* s, int slot, SlotParts* out);
+// Copy the ids this rank requests from its peers, for the `n` batches in slots first_slot.., into
+// one buffer laid out peer-major: out[pack_base[i*P + m] + k] = k-th id of batch i owned by m
+// (m != rank).  pack_base_dev: int64[n*P] in HBM.
+spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const int64_t* pack_base_dev,
+                                   int32_t* out_dev, hipStream_t st);
 // completion event of the group `slot` belongs to (NULL when nothing was sampled into it)
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot);
 

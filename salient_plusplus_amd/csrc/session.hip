@@ -65,13 +65,15 @@ __global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __res
 
 // exchange buffers of one slot-set
 struct XSet {
-  int64_t* cnt_dev = nullptr;   // [G*P] this rank's request counts, then [world*G*P] everybody's
+  int64_t* cnt_dev = nullptr;   // [G*P] this rank's request counts, [G*P] pack_base, [world*G*P] everybody's counts
   int64_t* cnt_host = nullptr;  // pinned mirror, same layout
+  int32_t* send_ids = nullptr;  // node ids this rank requests (peer-major, then batch)
+  int64_t send_ids_cap = 0;
   int32_t* recv_ids = nullptr;  // node ids the peers request from this rank (peer-major, then batch)
   int64_t recv_ids_cap = 0;
   char* send_rows = nullptr;    // their rows, same order
   int64_t send_rows_cap = 0;    // rows
-  char* recv_rows = nullptr;    // rows received for this rank's batches (batch-major, then peer)
+  char* recv_rows = nullptr;    // rows received for this rank's batches (peer-major, then batch)
   int64_t recv_rows_cap = 0;    // rows
   hipEvent_t cnt_ready = nullptr;
   hipEvent_t rows_done = nullptr;
@@ -295,67 +297,70 @@ static spp_status exchange_group(spp_session* s, int64_t g) {
       return SPP_ERR_CAPACITY;
     }
   }
-  // C1: what this rank requests from every owner, per batch; everybody learns everybody's requests
-  const size_t cnt_elems = (size_t)G * (size_t)P;
-  for (size_t k = 0; k < cnt_elems; ++k) x.cnt_host[k] = 0;
-  for (int i = 0; i < n; ++i)
-    for (int m = 0; m < P; ++m)
-      if (m != R) x.cnt_host[(size_t)i * P + m] = sp[i].pcnt[m];
-  int64_t* all_dev = x.cnt_dev + cnt_elems;
-  int64_t* all_host = x.cnt_host + cnt_elems;
-  SPP_HIP_TRY(hipMemcpyAsync(x.cnt_dev, x.cnt_host, cnt_elems * 8, hipMemcpyHostToDevice, st));
-  SPP_TRY(tr->all_gather(x.cnt_dev, all_dev, cnt_elems * 8, st));
-  SPP_HIP_TRY(hipMemcpyAsync(all_host, all_dev, cnt_elems * 8 * (size_t)P, hipMemcpyDeviceToHost, st));
-  SPP_HIP_TRY(hipEventRecord(x.cnt_ready, st));
-  SPP_HIP_TRY(hipEventSynchronize(x.cnt_ready));
-  auto req = [&](int m, int i) { return all_host[((size_t)m * G + i) * P + R]; };  // rows peer m wants from me
-
-  // layouts: requests served by this rank are peer-major (one contiguous span per peer and batch);
-  // rows coming back are batch-major so that a batch's assembly reads one region
-  int64_t off_req[SPP_MAX_PARTS][kMaxGroup];
-  int64_t total_req = 0, total_in = 0;
-  for (int m = 0; m < P; ++m)
+  // C1: what this rank requests from every owner, per batch; everybody learns everybody's requests.
+  // The same upload carries pack_base[i][m]: where batch i's ids for owner m go in the peer-major
+  // send buffer -- and, since rows come back in request order, where its rows land in recv_rows.
+  const size_t ge = (size_t)G * (size_t)P;
+  int64_t* mine = x.cnt_host;            // [G*P] request counts
+  int64_t* pbase = x.cnt_host + ge;      // [G*P] pack_base
+  int64_t* all_host = x.cnt_host + 2 * ge;
+  int64_t* all_dev = x.cnt_dev + 2 * ge;
+  int64_t want_from[SPP_MAX_PARTS], in_base[SPP_MAX_PARTS];
+  int64_t total_in = 0;
+  for (size_t k = 0; k < 2 * ge; ++k) x.cnt_host[k] = 0;
+  for (int m = 0; m < P; ++m) {
+    in_base[m] = total_in;
+    want_from[m] = 0;
     for (int i = 0; i < n; ++i) {
-      off_req[m][i] = total_req;
-      if (m != R) total_req += req(m, i);
-    }
-  for (int i = 0; i < n; ++i)
-    for (int m = 0; m < P; ++m) {
+      const int64_t c = (m != R) ? sp[i].pcnt[m] : 0;
+      mine[(size_t)i * P + m] = c;
+      pbase[(size_t)i * P + m] = total_in;
       x.recv_base[i][m] = total_in;
-      if (m != R) total_in += sp[i].pcnt[m];
+      total_in += c;
+      want_from[m] += c;
     }
+  }
+  SPP_HIP_TRY(hipMemcpyAsync(x.cnt_dev, x.cnt_host, 2 * ge * 8, hipMemcpyHostToDevice, st));
+  SPP_TRY(tr->all_gather(x.cnt_dev, all_dev, ge * 8, st));
+  SPP_HIP_TRY(hipMemcpyAsync(all_host, all_dev, ge * 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  SPP_HIP_TRY(hipEventRecord(x.cnt_ready, st));
+  // meanwhile: regroup the requested ids peer-major (needs only this rank's counts)
+  SPP_TRY(grow(s, (void**)&x.send_ids, &x.send_ids_cap, total_in, 4));
+  SPP_TRY(grow(s, (void**)&x.recv_rows, &x.recv_rows_cap, total_in, rb));
+  if (total_in > 0) SPP_TRY(sampler_pack_remote_ids(s->sampler, set * G, n, x.cnt_dev + ge, x.send_ids, st));
+  SPP_HIP_TRY(hipEventSynchronize(x.cnt_ready));
+  // rows peer m wants from this rank (all batches of the group, in batch order)
+  int64_t serve_for[SPP_MAX_PARTS], out_base[SPP_MAX_PARTS];
+  int64_t total_req = 0;
+  for (int m = 0; m < P; ++m) {
+    out_base[m] = total_req;
+    serve_for[m] = 0;
+    if (m == R) continue;
+    for (int i = 0; i < G; ++i) serve_for[m] += all_host[((size_t)m * G + i) * P + R];
+    total_req += serve_for[m];
+  }
   SPP_TRY(grow(s, (void**)&x.recv_ids, &x.recv_ids_cap, total_req, 4));
   SPP_TRY(grow(s, (void**)&x.send_rows, &x.send_rows_cap, total_req, rb));
-  SPP_TRY(grow(s, (void**)&x.recv_rows, &x.recv_rows_cap, total_in, rb));
 
-  // C2: node ids, int32, sent straight out of the slots' bucket lists
+  // C2: node ids, int32 -- one send and one receive per peer
   SPP_TRY(tr->group_begin());
   for (int m = 0; m < P; ++m) {
     if (m == R) continue;
-    for (int i = 0; i < n; ++i) {
-      int64_t base = 0;
-      for (int q = 0; q < m; ++q) base += sp[i].pcnt[q];
-      const int64_t c = sp[i].pcnt[m];
-      if (c > 0) SPP_TRY(tr->send(sp[i].parts + base, (size_t)c * 4, m, st));
-      const int64_t r = req(m, i);
-      if (r > 0) SPP_TRY(tr->recv(x.recv_ids + off_req[m][i], (size_t)r * 4, m, st));
-    }
+    if (want_from[m] > 0) SPP_TRY(tr->send(x.send_ids + in_base[m], (size_t)want_from[m] * 4, m, st));
+    if (serve_for[m] > 0) SPP_TRY(tr->recv(x.recv_ids + out_base[m], (size_t)serve_for[m] * 4, m, st));
   }
   SPP_TRY(tr->group_end(st));
   // K5: one gather of every requested row
   SPP_TRY(launch_serve(s, x.recv_ids, total_req, x.send_rows, st));
-  // C3: the rows
+  // C3: the rows, again one send and one receive per peer
   SPP_TRY(tr->group_begin());
   for (int m = 0; m < P; ++m) {
     if (m == R) continue;
-    for (int i = 0; i < n; ++i) {
-      const int64_t r = req(m, i);
-      if (r > 0) SPP_TRY(tr->send(x.send_rows + off_req[m][i] * rb, (size_t)(r * rb), m, st));
-      const int64_t c = sp[i].pcnt[m];
-      if (c > 0) SPP_TRY(tr->recv(x.recv_rows + x.recv_base[i][m] * rb, (size_t)(c * rb), m, st));
-    }
+    if (serve_for[m] > 0) SPP_TRY(tr->send(x.send_rows + out_base[m] * rb, (size_t)(serve_for[m] * rb), m, st));
+    if (want_from[m] > 0) SPP_TRY(tr->recv(x.recv_rows + in_base[m] * rb, (size_t)(want_from[m] * rb), m, st));
   }
   SPP_TRY(tr->group_end(st));
+  const size_t cnt_elems = ge;
   SPP_HIP_TRY(hipEventRecord(x.rows_done, st));
   x.rows_recorded = true;
   s->sent_bytes += total_req * rb + total_in * 4 + (int64_t)cnt_elems * 8;
@@ -419,8 +424,8 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   s->xsets.resize((size_t)s->num_sets);
   const size_t cnt_elems = (size_t)s->G * (size_t)s->P;
   for (auto& x : s->xsets) {
-    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_elems * 8 * (size_t)(s->P + 1)));
-    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_elems * 8 * (size_t)(s->P + 1), hipHostMallocDefault));
+    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_elems * 8 * (size_t)(s->P + 2)));
+    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_elems * 8 * (size_t)(s->P + 2), hipHostMallocDefault));
     SPP_HIP_TRY(hipEventCreateWithFlags(&x.cnt_ready, hipEventDisableTiming));
     SPP_HIP_TRY(hipEventCreateWithFlags(&x.rows_done, hipEventDisableTiming));
   }
@@ -433,6 +438,7 @@ static void exchange_teardown(spp_session* s) {
   for (auto& x : s->xsets) {
     if (x.cnt_dev) (void)hipFree(x.cnt_dev);
     if (x.cnt_host) (void)hipHostFree(x.cnt_host);
+    if (x.send_ids) (void)hipFree(x.send_ids);
     if (x.recv_ids) (void)hipFree(x.recv_ids);
     if (x.send_rows) (void)hipFree(x.send_rows);
     if (x.recv_rows) (void)hipFree(x.recv_rows);

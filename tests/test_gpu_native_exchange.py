@@ -168,3 +168,70 @@ def test_exchange_rejects_mismatched_communicator():
         fs.set_native_comm(None)
         for c in comms:
             c.close()
+
+
+def _products_rank(rank, P, comms, wl, nb, errors, out):
+    it = None
+    try:
+        from salient_plusplus_amd import fast_sampler as fs
+        from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+        torch.cuda.set_device(0)
+        fs.set_native_comm(comms[rank])
+        N, F = wl.num_nodes, wl.x.size(1)
+        offsets = torch.linspace(0, N, P + 1).long()
+        offsets[-1] = N
+        lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+        deg = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
+        deg[lo:hi] = -1
+        cv = torch.topk(deg, 20000).indices.sort().values
+        cache = fs.Cache(rank, P, cv, wl.x[cv].contiguous())
+        bs = wl.batch_size
+        idx = wl.train_idx[rank * nb * bs:(rank + 1) * nb * bs]
+        cfg = FastSamplerConfig(
+            x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=wl.x[lo:hi].contiguous(), y=wl.y.unsqueeze(-1),
+            rowptr=wl.rowptr, col=wl.col, idx=idx, batch_size=bs, sizes=wl.fanouts, skip_nonfull_batch=False,
+            pin_memory=False, distributed=True, partition_book=fs.RangePartitionBook(rank, P, offsets), cache=cache,
+            force_exact_num_batches=True, exact_num_batches=nb, count_remote_frequency=False, use_cache=True)
+        it = iter(FastSampler(2, 16, cfg))
+        assert it.session.native_exchange
+        k = 0
+        for proto in it:
+            assert torch.equal(proto.x, wl.x[proto.n_id]), f"rank {rank} batch {k}: assembled rows differ"
+            assert torch.equal(proto.sliced_cpu_labels.view(-1), wl.y[proto.n_id[:proto.sliced_cpu_labels.numel()]])
+            k += 1
+        assert k == nb
+        out[rank] = it.session.exchange_bytes()
+        it.session.close()
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        errors.append(f"rank {rank}: {e}\n{traceback.format_exc()}")
+        if it is not None:
+            it.session.close()
+        comms[rank].close()
+    finally:
+        from salient_plusplus_amd import fast_sampler as fs
+        fs.set_native_comm(None)
+
+
+def test_native_exchange_products_scale_two_ranks():
+    """Headline-size batches (~770k MFG nodes, ~330k remote rows each) through the native exchange:
+    20 batches per rank = 2.5 groups of 8, buffers grown on the fly, 20k-row VIP cache."""
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.synthetic import make_workload
+    wl = make_workload("S-products", device=torch.device("cuda", 0))
+    P, nb = 2, 20
+    comms = fs.NativeComm.local(P)
+    errors, out = [], {}
+    ts = [threading.Thread(target=_products_rank, args=(r, P, comms, wl, nb, errors, out)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    hung = [t for t in ts if t.is_alive()]
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not hung, "rank thread hung"
+    # what rank 0 sent in rows is what rank 1 received, and vice versa (ids + rows + counts)
+    assert out[0][0] > 1e8 and out[1][0] > 1e8
+    fs.clear_resident_cache()
