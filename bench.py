@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-products"))
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("SPP_MAX_SLOTS", "16")))
+    ap.add_argument("--slots", type=int, default=0,
+                    help="batch slots in flight (0 = 16 single-GPU, 32 distributed: 4 slot-sets of 8)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-step", action="store_true",
@@ -218,6 +219,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or a.force_distributed
+    if a.slots <= 0:
+        a.slots = 32 if distributed else int(os.environ.get("SPP_MAX_SLOTS", "16"))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -287,8 +290,24 @@ def main():
             sampler.idx = idx
             return DeviceDistributedPrefetcher([dev], iter(sampler), pipeline_on=True)
         feeder = EpochFeeder(make_iter, shuffler, lambda: shuffler.get_idx(rank))
+        # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
+        # all of them fall back to the torch.distributed transport together
+        try:
+            native = fs.native_comm() is not None
+            native_err = None
+        except Exception as e:  # noqa: BLE001
+            native, native_err = False, repr(e)
+        flag = torch.tensor([1 if native else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            if native_err and rank == 0:
+                print(f"[bench] native exchange unavailable: {native_err}", file=sys.stderr, flush=True)
+            os.environ["SPP_DIST_TRANSPORT"] = "torch"
+            native = False
         parallelism = f"dp{world}: features range-partitioned {world}-way, VIP(degree) cache " \
-                      f"{a.cache_frac:.0%} of N/P rows, RCCL all_to_all_single"
+                      f"{a.cache_frac:.0%} of N/P rows, " + \
+                      ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
+                       if native else "torch.distributed all_to_all_single per batch")
 
     # ---- warmup ----
     for _ in range(a.warmup):
@@ -311,7 +330,9 @@ def main():
     dt = time.perf_counter() - t0
     # gather-kernel time, measured live with HIP events on the launching stream
     ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
-    prof_kind = 1 if distributed else 0      # SPP_PROF_ASSEMBLE / SPP_PROF_GATHER
+    # SPP_PROF_GATHER: the fused delivery launch (also assembles x with the native exchange);
+    # SPP_PROF_ASSEMBLE: the stand-alone assembly of the torch.distributed transport
+    prof_kind = 1 if (distributed and not native) else 0
     nat.check(L.spp_profile_read(prof_kind, C.byref(ms), C.byref(n_launch), C.byref(rows)))
     L.spp_profile_enable(0)
 
@@ -334,7 +355,8 @@ def main():
         x_ms = ms.value
         launches_x = n_launch.value
         achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_assemble" if distributed else "k_deliver (gather_rows_body)",
+        roof = {"bound": "hbm", "kernel": "k_assemble" if prof_kind == 1 else
+                ("k_deliver (assemble from local/received/cache rows)" if distributed else "k_deliver (gather_rows_body)"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,

@@ -31,6 +31,9 @@ __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "
            "set_native_comm"]
 
 _MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "16"))
+# distributed Sessions pipeline three stages (sample -> exchange -> consume), one slot-set each plus
+# one in hand: 4 sets of 8
+_MAX_SLOTS_DIST = int(os.environ.get("SPP_MAX_SLOTS_DIST", "32"))
 
 
 # --------------------------------------------------------------------------------------------
@@ -417,7 +420,7 @@ class Session:
             raise RuntimeError("force_exact_num_batches needs idx.numel() / exact_num_batches >= 1")
         nb, max_batch = _host_ranges(n, int(config.batch_size), bool(config.skip_nonfull_batch), force_exact,
                                      int(config.exact_num_batches))
-        slots = max(1, min(int(max_items_in_queue), _MAX_SLOTS, max(nb, 1)))
+        slots = max(1, min(int(max_items_in_queue), _MAX_SLOTS_DIST if self._distributed else _MAX_SLOTS, max(nb, 1)))
         self._part = self._partition_cfg() if self._distributed else None
         self._pool_entry = _SamplerPool.acquire(self._rowptr, self._col, self._sizes, max_batch, slots,
                                                 self._dev.index, part=self._part)

@@ -96,6 +96,7 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
     (2, False, 3, 32, 6),       # one group holds all batches
     (2, True, 7, 16, 4),        # several groups, 2-slot sets, ragged last group, VIP cache
     (3, True, 5, 24, 16),       # three ranks
+    (2, True, 37, 4, 32),       # four slot-sets of 8 in flight, ragged tail
 ])
 def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
     from salient_plusplus_amd import fast_sampler as fs
