@@ -97,12 +97,13 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
     (2, True, 7, 16, 4),        # several groups, 2-slot sets, ragged last group, VIP cache
     (3, True, 5, 24, 16),       # three ranks
     (2, True, 37, 4, 32),       # four slot-sets of 8 in flight, ragged tail
+    (8, True, 9, 8, 32),        # the scaling bench's rank count
 ])
 def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
     from salient_plusplus_amd import fast_sampler as fs
     g = _graph()
     n = g["rowptr"].shape[0] - 1
-    offsets = [0, 1400, n] if P == 2 else [0, 900, 2100, n]
+    offsets = {2: [0, 1400, n], 3: [0, 900, 2100, n]}.get(P) or [int(v) for v in np.linspace(0, n, P + 1)]
     comms = fs.NativeComm.local(P)
     errors, stats = [], {}
     ts = [threading.Thread(target=_run_rank, args=(r, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stats))
