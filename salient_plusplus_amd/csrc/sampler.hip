@@ -46,6 +46,10 @@
 
 #include "gather_body.cuh"
 #include "partition_common.cuh"
+
+#ifndef SPP_TILE_NT
+#define SPP_TILE_NT 1024
+#endif
 #include "mt19937.cuh"
 #include "sampler_internal.h"
 
@@ -68,6 +72,7 @@ struct DedupGeom {
 };
 constexpr int kMaxBucketsLog2 = 12;
 constexpr int kMaxBuckets = 1 << kMaxBucketsLog2;
+constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile kernels (more waves per tile: latency bound)
 constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
                                             // one global atomic reserves room for several edges)
 constexpr uint32_t kPending = 0x80000000u;  // known-list value = kPending | edge position of the previous hop
@@ -404,24 +409,24 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // ----------------------------------------------------------------------------------------------
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
+__global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
                                                       DedupGeom g) {
   __shared__ int32_t lh[kMaxBuckets];
-  __shared__ int32_t lscan[kNT / kWave + 1];
+  __shared__ int32_t lscan[kTileNT / kWave + 1];
   __shared__ int is_last;
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t E = s.st->error ? 0 : s.st->E[h];
   const int64_t base = (int64_t)blockIdx.x * kBucketTile;
   if (base >= E && blockIdx.x != 0) return;  // tile 0 always takes part (E may be 0)
   const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
-  for (int b = threadIdx.x; b < g.nb; b += kNT) lh[b] = 0;
+  for (int b = threadIdx.x; b < g.nb; b += kTileNT) lh[b] = 0;
   __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
     const int64_t p = base + k;
     if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < g.nb; b += kNT)
+  for (int b = threadIdx.x; b < g.nb; b += kTileNT)
     if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
   // last tile: exclusive scan of the bucket counts -> offsets and scatter cursors; counts re-zeroed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own atomics before the barrier
@@ -430,11 +435,11 @@ __global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict_
   __syncthreads();
   if (!is_last) return;
   int32_t carry = 0;
-  for (int32_t bb = 0; bb < g.nb; bb += kNT) {
+  for (int32_t bb = 0; bb < g.nb; bb += kTileNT) {
     const int32_t b = bb + threadIdx.x;
     const int32_t v = (b < g.nb) ? acquire_i32(&s.bcount[b]) : 0;
     int32_t tot;
-    const int32_t ex = block_exclusive_scan<int32_t, kNT>(v, lscan, &tot);
+    const int32_t ex = block_exclusive_scan<int32_t, kTileNT>(v, lscan, &tot);
     if (b < g.nb) {
       s.boff[b] = carry + ex;
       s.bcur[b] = carry + ex;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_hist(const SlotPtrs* __restrict_
   if (threadIdx.x == 0) s.boff[g.nb] = carry;
 }
 
-__global__ __launch_bounds__(kNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
                                                          int32_t h, DedupGeom g) {
   __shared__ int32_t lh[kMaxBuckets];    // tile histogram, then running cursor inside the reservation
   __shared__ int32_t lbase[kMaxBuckets]; // start of this tile's reservation in each bucket
@@ -454,20 +459,20 @@ __global__ __launch_bounds__(kNT) void k_bucket_scatter(const SlotPtrs* __restri
   const int32_t E = s.st->E[h];
   const int64_t base = (int64_t)blockIdx.x * kBucketTile;
   if (base >= E || s.st->error) return;
-  for (int b = threadIdx.x; b < g.nb; b += kNT) lh[b] = 0;
+  for (int b = threadIdx.x; b < g.nb; b += kTileNT) lh[b] = 0;
   __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
     const int64_t p = base + k;
     if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < g.nb; b += kNT) {
+  for (int b = threadIdx.x; b < g.nb; b += kTileNT) {
     const int32_t c = lh[b];
     lbase[b] = c ? atomicAdd(&s.bcur[b], c) : 0;
     lh[b] = 0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kNT) {
+  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
     const int64_t p = base + k;
     if (p < E) {
       const uint32_t c = (uint32_t)s.cval[p];
@@ -1251,8 +1256,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
-    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom);
+    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, geom);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, geom);
     if (s->lds_log2 == 12)
       hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
                          geom);
