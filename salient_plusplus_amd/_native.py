@@ -42,7 +42,8 @@ class MfgOut(C.Structure):
 
 class ExchangeCfg(C.Structure):
     _fields_ = [("comm", p), ("x_local_dev", p), ("x_local_rows", i64), ("row_bytes", i64),
-                ("cache_feats_dev", p), ("cache_rows", i64)]
+                ("cache_feats_dev", p), ("cache_rows", i64), ("x_local_stride_bytes", i64),
+                ("cache_stride_bytes", i64)]
 
 
 class SessionCfg(C.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "spp_mt19937_fill": (C.c_int, [u32, i64, i64, p, p]),
     "spp_batch_seed": (u32, [i32]),
     "spp_gather_rows": (C.c_int, [p, i64, i64, p, C.c_int, i64, i64, p, p]),
+    "spp_gather_rows_strided": (C.c_int, [p, i64, i64, i64, p, C.c_int, i64, i64, p, p]),
     "spp_to_row_major": (C.c_int, [p, i64, i64, C.c_int, p, p]),
     "spp_sampler_create": (C.c_int, [C.POINTER(SamplerCfg), C.POINTER(p)]),
     "spp_sampler_destroy": (None, [p]),
@@ -78,20 +80,20 @@ SIGNATURES = {
     "spp_sampler_sample": (C.c_int, [p, i32, p, i64, u32, i64, p]),
     "spp_sampler_wait": (C.c_int, [p, i32, C.POINTER(MfgCounts)]),
     "spp_sampler_export": (C.c_int, [p, i32, C.POINTER(MfgOut), p]),
-    "spp_sampler_gather": (C.c_int, [p, i32, p, i64, i64, i64, p, p]),
+    "spp_sampler_gather": (C.c_int, [p, i32, p, i64, i64, i64, i64, p, p]),
     "spp_nid2partid": (C.c_int, [p, i32, p, i64, p, p]),
     "spp_cache_build_map": (C.c_int, [p, i64, p, i64, p]),
     "spp_cache_lookup": (C.c_int, [p, i64, p, i64, p, p, p]),
     "spp_partition_workspace_bytes": (i64, [i64]),
     "spp_partition_batch": (C.c_int, [p, i64, p, i32, i32, i32, p, i64, i64, p, p, p, p, p, p, i64, p]),
-    "spp_assemble_features": (C.c_int, [p, p, i64, p, i32, i32, i64, p, i64, p, p, p, i64, p, p]),
+    "spp_assemble_features": (C.c_int, [p, p, i64, p, i32, i32, i64, p, i64, p, p, p, i64, i64, i64, p, p]),
     "spp_session_create": (C.c_int, [C.POINTER(SessionCfg), C.POINTER(p)]),
     "spp_session_destroy": (None, [p]),
     "spp_session_num_total_batches": (i64, [p]),
     "spp_session_num_consumed_batches": (i64, [p]),
     "spp_session_batch_ranges": (C.c_int, [p, p]),
     "spp_session_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
-    "spp_session_export": (C.c_int, [p, C.POINTER(MfgOut), p, i64, i64, p, p, i64, i64, p, p]),
+    "spp_session_export": (C.c_int, [p, C.POINTER(MfgOut), p, i64, i64, i64, p, p, i64, i64, p, p]),
     "spp_session_blocked_us": (i64, [p]),
     "spp_session_blocked_occasions": (i64, [p]),
     "spp_session_sampler": (p, [p]),

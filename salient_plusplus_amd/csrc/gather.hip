@@ -13,15 +13,16 @@ template <int VEC, typename IdxT, bool kNT>
 __global__ __launch_bounds__(kGatherThreads) void k_gather_rows(const char* __restrict__ src,
                                                                  const IdxT* __restrict__ idx, int64_t n,
                                                                  int64_t row_bytes, int chunks, int lpr_log2,
-                                                                 char* __restrict__ dst) {
-  gather_rows_body<VEC, IdxT, kNT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x);
+                                                                 char* __restrict__ dst, int64_t src_stride) {
+  gather_rows_body<VEC, IdxT, kNT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x, src_stride);
 }
 
 template <typename IdxT>
-static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* idx, int64_t n, void* dst,
-                                hipStream_t st) {
+static spp_status launch_gather(const void* src, int64_t row_bytes, int64_t src_stride, const IdxT* idx, int64_t n,
+                                void* dst, hipStream_t st) {
   if (n <= 0 || row_bytes <= 0) return SPP_OK;
-  const GatherGeom gg = gather_geometry(src, dst, row_bytes, n);
+  if (src_stride <= 0) src_stride = row_bytes;
+  const GatherGeom gg = gather_geometry(src, dst, row_bytes, n, src_stride);
   const int chunks = gg.chunks, lpr_log2 = gg.lpr_log2;
   const int64_t grid = gg.grid;
   const char* s = static_cast<const char*>(src);
@@ -32,10 +33,10 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* 
   do {                                                                                                          \
     if (nt)                                                                                                     \
       hipLaunchKernelGGL((k_gather_rows<V, IdxT, true>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s,  \
-                         idx, n, row_bytes, chunks, lpr_log2, d);                                               \
+                         idx, n, row_bytes, chunks, lpr_log2, d, src_stride);                                   \
     else                                                                                                        \
       hipLaunchKernelGGL((k_gather_rows<V, IdxT, false>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, \
-                         idx, n, row_bytes, chunks, lpr_log2, d);                                               \
+                         idx, n, row_bytes, chunks, lpr_log2, d, src_stride);                                   \
   } while (0)
   switch (gg.vec) {
     case 16: SPP_LAUNCH_GATHER(16); break;
@@ -51,9 +52,9 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, const IdxT* 
 }
 
 // used by sampler.hip (int32 node list of a slot)
-spp_status gather_rows_i32(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n, void* dst,
-                           hipStream_t st) {
-  return launch_gather<int32_t>(src, row_bytes, idx, n, dst, st);
+spp_status gather_rows_i32(const void* src, int64_t row_bytes, int64_t src_stride, const int32_t* idx, int64_t n,
+                           void* dst, hipStream_t st) {
+  return launch_gather<int32_t>(src, row_bytes, src_stride, idx, n, dst, st);
 }
 
 // ---- to_row_major (reference fast_sampler.cpp:281-308): out[r*tc + c] = in[c*tr + r] ----
@@ -79,7 +80,17 @@ __global__ __launch_bounds__(256) void k_to_row_major(const T* __restrict__ in, 
 extern "C" spp_status spp_gather_rows(const void* src_dev, int64_t src_rows, int64_t row_bytes, const void* idx_dev,
                                       int idx_elem_bytes, int64_t n_idx, int64_t n_out, void* dst_dev,
                                       void* stream) {
+  return spp_gather_rows_strided(src_dev, src_rows, row_bytes, row_bytes, idx_dev, idx_elem_bytes, n_idx, n_out,
+                                 dst_dev, stream);
+}
+
+extern "C" spp_status spp_gather_rows_strided(const void* src_dev, int64_t src_rows, int64_t row_bytes,
+                                              int64_t src_stride_bytes, const void* idx_dev, int idx_elem_bytes,
+                                              int64_t n_idx, int64_t n_out, void* dst_dev, void* stream) {
   SPP_REQUIRE(row_bytes >= 0 && n_idx >= 0 && n_out >= 0, "spp_gather_rows: negative size");
+  SPP_REQUIRE(src_stride_bytes == 0 || src_stride_bytes >= row_bytes,
+              "spp_gather_rows: source stride %lld smaller than the row (%lld bytes)", (long long)src_stride_bytes,
+              (long long)row_bytes);
   SPP_REQUIRE(idx_elem_bytes == 8 || idx_elem_bytes == 4, "spp_gather_rows: idx_elem_bytes must be 4 or 8, got %d",
               idx_elem_bytes);
   const int64_t n = n_idx < n_out ? n_idx : n_out;  // reference :253  min(idx.numel(), n)
@@ -87,10 +98,10 @@ extern "C" spp_status spp_gather_rows(const void* src_dev, int64_t src_rows, int
   SPP_REQUIRE(src_dev && idx_dev && dst_dev, "spp_gather_rows: NULL buffer");
   (void)src_rows;
   if (idx_elem_bytes == 8)
-    return spp::launch_gather<int64_t>(src_dev, row_bytes, static_cast<const int64_t*>(idx_dev), n, dst_dev,
-                                       spp::as_stream(stream));
-  return spp::launch_gather<int32_t>(src_dev, row_bytes, static_cast<const int32_t*>(idx_dev), n, dst_dev,
-                                     spp::as_stream(stream));
+    return spp::launch_gather<int64_t>(src_dev, row_bytes, src_stride_bytes, static_cast<const int64_t*>(idx_dev), n,
+                                       dst_dev, spp::as_stream(stream));
+  return spp::launch_gather<int32_t>(src_dev, row_bytes, src_stride_bytes, static_cast<const int32_t*>(idx_dev), n,
+                                     dst_dev, spp::as_stream(stream));
 }
 
 extern "C" spp_status spp_to_row_major(const void* src_dev, int64_t rows, int64_t cols, int elem_bytes, void* dst_dev,

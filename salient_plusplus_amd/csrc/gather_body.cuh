@@ -31,9 +31,11 @@ struct GatherGeom {
   int64_t grid;   // workgroups wanted
 };
 
-static inline GatherGeom gather_geometry(const void* src, const void* dst, int64_t row_bytes, int64_t n) {
+static inline GatherGeom gather_geometry(const void* src, const void* dst, int64_t row_bytes, int64_t n,
+                                         int64_t src_stride = 0) {
   GatherGeom g{};
-  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)row_bytes;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)row_bytes |
+                      (uintptr_t)src_stride;
   g.vec = 16;
   while (g.vec > 1 && (a % g.vec) != 0) g.vec >>= 1;
   g.chunks = (int)(row_bytes / g.vec);
@@ -92,9 +94,10 @@ __device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t 
 template <int VEC, typename IdxT, bool kNT = false>
 __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
                                                  int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
-                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks,
+                                                 int64_t src_stride) {
   if (n <= 0) return;
-  move_rows_body<VEC, kNT>([=](int64_t r) { return src + (int64_t)idx[r] * row_bytes; }, n, row_bytes, chunks,
+  move_rows_body<VEC, kNT>([=](int64_t r) { return src + (int64_t)idx[r] * src_stride; }, n, row_bytes, chunks,
                            lpr_log2, dst, vblock, nvblocks);
 }
 

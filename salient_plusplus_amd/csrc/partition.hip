@@ -176,6 +176,7 @@ struct AsmArgs {
   const char* cache_feats;
   const int64_t* cached_nids;
   int64_t row_bytes;
+  int64_t x_local_stride, cache_stride;
   char* out;
 };
 
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(kPT) void k_assemble(AsmArgs a, int chunks, int lpr
     int m = 0;
     while (m < a.P && j >= a.seg_start[m + 1]) ++m;
     const char* src;
-    if (m == a.rank) src = a.x_local + (a.n_id[r] - a.rank_offset) * a.row_bytes;
-    else if (m == a.P) src = a.cache_feats + a.cached_nids[j - a.seg_start[a.P]] * a.row_bytes;
+    if (m == a.rank) src = a.x_local + (a.n_id[r] - a.rank_offset) * a.x_local_stride;
+    else if (m == a.P) src = a.cache_feats + a.cached_nids[j - a.seg_start[a.P]] * a.cache_stride;
     else src = a.recv + (a.recv_base[m] + (j - a.seg_start[m])) * a.row_bytes;
     const V* s = reinterpret_cast<const V*>(src);
     V* d = reinterpret_cast<V*>(a.out + r * a.row_bytes);
@@ -307,7 +308,8 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
                                             const int64_t* seg_start_host, int32_t P, int32_t rank, int64_t rank_offset,
                                             const void* x_local_dev, int64_t x_local_rows, const void* recv_dev,
                                             const void* cache_feats_dev, const int64_t* cached_nids_dev,
-                                            int64_t row_bytes, void* x_out_dev, void* stream) {
+                                            int64_t row_bytes, int64_t x_local_stride_bytes,
+                                            int64_t cache_stride_bytes, void* x_out_dev, void* stream) {
   SPP_REQUIRE(P >= 1 && P <= SPP_MAX_PARTS && rank >= 0 && rank < P, "spp_assemble_features: bad P/rank");
   SPP_REQUIRE(seg_start_host, "spp_assemble_features: seg_start_host is NULL");
   if (U <= 0 || row_bytes <= 0) return SPP_OK;
@@ -337,10 +339,14 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
   a.cache_feats = static_cast<const char*>(cache_feats_dev);
   a.cached_nids = cached_nids_dev;
   a.row_bytes = row_bytes;
+  a.x_local_stride = x_local_stride_bytes > 0 ? x_local_stride_bytes : row_bytes;
+  a.cache_stride = cache_stride_bytes > 0 ? cache_stride_bytes : row_bytes;
+  SPP_REQUIRE(a.x_local_stride >= row_bytes && a.cache_stride >= row_bytes,
+              "spp_assemble_features: row strides must be at least row_bytes");
   a.out = static_cast<char*>(x_out_dev);
   const uintptr_t al = reinterpret_cast<uintptr_t>(x_local_dev) | reinterpret_cast<uintptr_t>(recv_dev) |
                        reinterpret_cast<uintptr_t>(cache_feats_dev) | reinterpret_cast<uintptr_t>(x_out_dev) |
-                       (uintptr_t)row_bytes;
+                       (uintptr_t)row_bytes | (uintptr_t)a.x_local_stride | (uintptr_t)a.cache_stride;
   int vec = 16;
   while (vec > 1 && (al % vec) != 0) vec >>= 1;
   const int chunks = (int)(row_bytes / vec);

@@ -55,8 +55,8 @@
 
 namespace spp {
 
-spp_status gather_rows_i32(const void* src, int64_t row_bytes, const int32_t* idx, int64_t n, void* dst,
-                           hipStream_t st);
+spp_status gather_rows_i32(const void* src, int64_t row_bytes, int64_t src_stride, const int32_t* idx, int64_t n,
+                           void* dst, hipStream_t st);
 
 constexpr int kNT = 256;         // workgroup size of the per-target / per-edge kernels
 constexpr int kFastMaxFanout = 32;
@@ -810,7 +810,7 @@ struct DeliverArgs {
   // x = x_src[n_id[:U], :]
   const char* x_src;
   char* x_dst;
-  int64_t x_rows, x_row_bytes;
+  int64_t x_rows, x_row_bytes, x_src_stride;
   int x_chunks, x_lpr_log2;
   int32_t nb_x, nb_e, nb_y;
   // y = y_src[n_id[:bs], :]
@@ -823,6 +823,7 @@ struct DeliverArgs {
   int64_t rank_offset;
   const char* recv;
   const char* cache;
+  int64_t cache_stride;
   const int32_t* pperm;
   const int32_t* pcached;
   int32_t seg_start[SPP_MAX_PARTS + 2];
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
   if (b < a.nb_x) {
     if (!a.asm_on) {
       gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
-                                     a.nb_x);
+                                     a.nb_x, a.x_src_stride);
     } else {
       // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes
       move_rows_body<VEC, false>(
@@ -844,8 +845,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
             const int32_t j = a.pperm[r];
             int m = 0;
             while (m < a.P && j >= a.seg_start[m + 1]) ++m;
-            if (m == a.rank) return a.x_src + ((int64_t)a.n_ids[r] - a.rank_offset) * a.x_row_bytes;
-            if (m == a.P) return a.cache + (int64_t)a.pcached[j - a.seg_start[m]] * a.x_row_bytes;
+            if (m == a.rank) return a.x_src + ((int64_t)a.n_ids[r] - a.rank_offset) * a.x_src_stride;
+            if (m == a.P) return a.cache + (int64_t)a.pcached[j - a.seg_start[m]] * a.cache_stride;
             return a.recv + (a.recv_base[m] + (j - a.seg_start[m])) * a.x_row_bytes;
           },
           a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b, a.nb_x);
@@ -1317,8 +1318,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 // Fused delivery of the (waited) batch in `slot` on the caller's stream: MFG widening + x and y
 // row gathers in one launch.  Any of mfg / x / y may be absent.
 spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
-                           void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
-                           const AssembleSrc* asrc, hipStream_t st) {
+                           int64_t x_src_stride, void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows,
+                           void* y_dst, const AssembleSrc* asrc, hipStream_t st) {
   SlotHost& sl = s->slots[(size_t)slot];
   if (!sl.sampled || !sl.waited) {
     set_error("spp_session_export: slot %d must be sampled and waited first", slot);
@@ -1361,6 +1362,8 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   if (asrc) {
     SPP_REQUIRE(s->part.P > 0, "sampler_deliver: feature assembly needs ownership bucketing");
     x_src = asrc->x_local;
+    x_src_stride = asrc->x_local_stride;
+    a.cache_stride = asrc->cache_stride > 0 ? asrc->cache_stride : x_row_bytes;
     a.asm_on = 1;
     a.P = s->part.P;
     a.rank = s->part.rank;
@@ -1379,9 +1382,15 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
     SPP_REQUIRE(hs->pcnt[s->part.P] == 0 || asrc->cache, "sampler_deliver: cache hits without cache rows");
   }
   if (x_src && x_dst && U > 0 && x_row_bytes > 0) {
+    if (x_src_stride <= 0) x_src_stride = x_row_bytes;
+    SPP_REQUIRE(x_src_stride >= x_row_bytes, "spp_session_export: source stride %lld smaller than the row (%lld bytes)",
+                (long long)x_src_stride, (long long)x_row_bytes);
     uintptr_t align_probe = reinterpret_cast<uintptr_t>(x_src);
-    if (asrc) align_probe |= reinterpret_cast<uintptr_t>(asrc->recv) | reinterpret_cast<uintptr_t>(asrc->cache);
-    const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U);
+    if (asrc)
+      align_probe |= reinterpret_cast<uintptr_t>(asrc->recv) | reinterpret_cast<uintptr_t>(asrc->cache) |
+                     (uintptr_t)a.cache_stride;
+    const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U, x_src_stride);
+    a.x_src_stride = x_src_stride;
     vec = gg.vec;
     a.x_src = static_cast<const char*>(x_src);
     a.x_dst = static_cast<char*>(x_dst);
@@ -1529,7 +1538,8 @@ extern "C" spp_status spp_sampler_export(spp_sampler* s, int32_t slot, const spp
 }
 
 extern "C" spp_status spp_sampler_gather(spp_sampler* s, int32_t slot, const void* src_dev, int64_t src_rows,
-                                         int64_t row_bytes, int64_t n_rows, void* dst_dev, void* stream) {
+                                         int64_t row_bytes, int64_t src_stride_bytes, int64_t n_rows, void* dst_dev,
+                                         void* stream) {
   SPP_REQUIRE(s && slot >= 0 && slot < (int32_t)s->slots.size(), "spp_sampler_gather: bad sampler/slot");
   SlotHost& sl = s->slots[slot];
   if (!sl.sampled || !sl.waited) {
@@ -1541,5 +1551,6 @@ extern "C" spp_status spp_sampler_gather(spp_sampler* s, int32_t slot, const voi
   if (n == 0 || row_bytes == 0) return SPP_OK;
   SPP_REQUIRE(src_dev && dst_dev, "spp_sampler_gather: NULL buffer");
   (void)src_rows;
-  return gather_rows_i32(src_dev, row_bytes, sl.p.n_ids, n, dst_dev, as_stream(stream));
+  SPP_REQUIRE(src_stride_bytes == 0 || src_stride_bytes >= row_bytes, "spp_sampler_gather: bad source stride");
+  return gather_rows_i32(src_dev, row_bytes, src_stride_bytes, sl.p.n_ids, n, dst_dev, as_stream(stream));
 }

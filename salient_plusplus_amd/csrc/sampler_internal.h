@@ -30,8 +30,9 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 // recv + recv_base[m] rows (rows received from peer m for THIS batch).
 struct AssembleSrc {
   const char* x_local;
-  const char* recv;
+  const char* recv;      // dense rows
   const char* cache;
+  int64_t x_local_stride, cache_stride;  // bytes between rows
   int64_t recv_base[SPP_MAX_PARTS];
 };
 
@@ -39,8 +40,8 @@ struct AssembleSrc {
 // MFG widening (mfg may be NULL), x = x_src[n_id,:] (or, with `asrc`, assembled from the local
 // partition / received rows / cache), y = y_src[n_id[:y_rows],:].
 spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
-                           void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows, void* y_dst,
-                           const AssembleSrc* asrc, hipStream_t st);
+                           int64_t x_src_stride, void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows,
+                           void* y_dst, const AssembleSrc* asrc, hipStream_t st);
 
 // Ownership buckets of the batch in `slot` (valid once the group's completion event has been
 // synchronised): device arrays and the host mirror of the bucket sizes.

@@ -50,13 +50,14 @@ namespace spp {
 template <int VEC>
 __global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __restrict__ x_local, int64_t x_rows,
                                                                const int32_t* __restrict__ ids, int64_t n,
-                                                               int64_t rank_offset, int64_t row_bytes, int chunks,
-                                                               int lpr_log2, char* __restrict__ out) {
+                                                               int64_t rank_offset, int64_t row_bytes,
+                                                               int64_t src_stride, int chunks, int lpr_log2,
+                                                               char* __restrict__ out) {
   move_rows_body<VEC, false>(
       [=](int64_t j) -> const char* {
         int64_t r = (int64_t)ids[j] - rank_offset;
         r = r < 0 ? 0 : (r >= x_rows ? x_rows - 1 : r);  // a peer only asks for rows this rank owns
-        return x_local + r * row_bytes;
+        return x_local + r * src_stride;
       },
       n, row_bytes, chunks, lpr_log2, out, blockIdx.x, gridDim.x);
 }
@@ -259,11 +260,11 @@ static spp_status grow(spp_session* s, void** buf, int64_t* cap, int64_t need, i
 
 static spp_status launch_serve(spp_session* s, const int32_t* ids, int64_t n, char* out, hipStream_t st) {
   if (n <= 0) return SPP_OK;
-  const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n);
+  const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n, s->xcfg.x_local_stride_bytes);
   const char* x = static_cast<const char*>(s->xcfg.x_local_dev);
 #define SPP_SERVE(V)                                                                                              \
   hipLaunchKernelGGL(k_serve_rows<V>, dim3((unsigned)gg.grid), dim3(kGatherThreads), 0, st, x, s->xcfg.x_local_rows, \
-                     ids, n, s->rank_offset, s->xcfg.row_bytes, gg.chunks, gg.lpr_log2, out)
+                     ids, n, s->rank_offset, s->xcfg.row_bytes, s->xcfg.x_local_stride_bytes, gg.chunks, gg.lpr_log2, out)
   switch (gg.vec) {
     case 16: SPP_SERVE(16); break;
     case 8: SPP_SERVE(8); break;
@@ -417,6 +418,10 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   SPP_REQUIRE(!part.use_cache || xc->cache_feats_dev || xc->cache_rows == 0,
               "spp_session_create: use_cache without cache rows");
   s->xcfg = *xc;
+  if (s->xcfg.x_local_stride_bytes <= 0) s->xcfg.x_local_stride_bytes = xc->row_bytes;
+  if (s->xcfg.cache_stride_bytes <= 0) s->xcfg.cache_stride_bytes = xc->row_bytes;
+  SPP_REQUIRE(s->xcfg.x_local_stride_bytes >= xc->row_bytes && s->xcfg.cache_stride_bytes >= xc->row_bytes,
+              "spp_session_create: row strides must be at least row_bytes");
   s->P = part.num_parts;
   s->rank = part.rank;
   s->rank_offset = part.offsets[part.rank];
@@ -630,8 +635,9 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
 }
 
 extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg, const void* x_src_dev, int64_t x_rows,
-                                         int64_t x_row_bytes, void* x_out_dev, const void* y_src_dev, int64_t y_rows,
-                                         int64_t y_row_bytes, void* y_out_dev, void* stream) {
+                                         int64_t x_row_bytes, int64_t x_src_stride_bytes, void* x_out_dev,
+                                         const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,
+                                         void* stream) {
   SPP_REQUIRE(s, "spp_session_export: NULL session");
   if (s->current_slot < 0) {
     set_error("spp_session_export: no current batch (call spp_session_next first)");
@@ -653,12 +659,14 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
     src.x_local = static_cast<const char*>(s->xcfg.x_local_dev);
     src.recv = x.recv_rows;
     src.cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
+    src.x_local_stride = s->xcfg.x_local_stride_bytes;
+    src.cache_stride = s->xcfg.cache_stride_bytes;
     for (int m = 0; m < s->P; ++m) src.recv_base[m] = x.recv_base[b % s->G][m];
-    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, nullptr, s->xcfg.row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
-                            y_out_dev, &src, as_stream(stream)));
+    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, nullptr, s->xcfg.row_bytes, 0, x_out_dev, y_src_dev, y_row_bytes,
+                            bs, y_out_dev, &src, as_stream(stream)));
   } else {
-    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_out_dev, y_src_dev, y_row_bytes, bs,
-                            y_out_dev, nullptr, as_stream(stream)));
+    SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_src_stride_bytes, x_out_dev, y_src_dev,
+                            y_row_bytes, bs, y_out_dev, nullptr, as_stream(stream)));
   }
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
   s->export_recorded[(size_t)slot] = 1;

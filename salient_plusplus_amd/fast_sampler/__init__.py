@@ -86,9 +86,54 @@ class _ResidentCache:
             self._d[key] = (t, r)          # keep `t` alive so the key cannot be recycled
             return r
 
+    def get_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """HBM-resident copy of a 2-D feature table with rows padded to the HBM fetch granule
+        (a strided [N, F] view of [N, stride] storage; see _row_stride_elems)."""
+        dev = _device()
+        se = _row_stride_elems(t.size(1), t.element_size()) if t.dim() == 2 else 0
+        if t.dim() != 2 or se == t.size(1):
+            return self.get(t)
+        key = ("rows", t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, dev.index)
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is not None and hit[0] is t:
+                return hit[1]
+            buf = torch.empty((t.size(0), se), dtype=t.dtype, device=dev)
+            r = buf[:, :t.size(1)]
+            r.copy_(t, non_blocking=False)
+            self._d[key] = (t, r)
+            return r
+
     def clear(self):
         with self._lock:
             self._d.clear()
+
+
+def _row_stride_elems(cols: int, elem_bytes: int) -> int:
+    """Elements between consecutive rows of a resident feature table.  HBM is fetched in 128-B
+    granules: a dense 200-B row straddles 2.56 of them on average, a row that starts on a granule
+    boundary exactly 2 -- 22 % less gather traffic for 28 % more table (288 GB of HBM per GPU).
+    Rows shorter than a granule are padded to the next power of two so that none straddles one."""
+    rb = cols * elem_bytes
+    if rb < 16 or os.environ.get("SPP_ROW_PAD", "1") == "0":
+        return cols
+    if rb >= 128:
+        stride = (rb + 127) // 128 * 128
+        if stride * 3 > rb * 4:                  # more than 1/3 padding: settle for 64-B alignment, or none
+            stride = (rb + 63) // 64 * 64
+            if stride * 3 > rb * 4:
+                return cols
+    else:
+        stride = 16
+        while stride < rb:
+            stride *= 2
+    if stride % elem_bytes:
+        return cols
+    return stride // elem_bytes
+
+
+def _stride_bytes(t: Optional[torch.Tensor]) -> int:
+    return int(t.stride(0)) * t.element_size() if t is not None and t.dim() == 2 and t.size(0) > 1 else 0
 
 
 _resident = _ResidentCache()
@@ -183,7 +228,8 @@ class Cache:
 
     def device_features(self) -> torch.Tensor:
         if self._features_dev is None:
-            self._features_dev = self.cached_features.to(_device()).contiguous()
+            self._features_dev = _resident.get_rows(self.cached_features) if self.cached_features.dim() == 2 \
+                else self.cached_features.to(_device()).contiguous()
         return self._features_dev
 
     def _lookup(self, nids: torch.Tensor, want_flag: bool):
@@ -402,11 +448,12 @@ class Session:
             if len(parts) == 2:
                 self._x = _resident_concat(xg, xc)
             elif len(parts) == 1:
-                self._x = _resident.get(parts[0])
+                self._x = _resident.get_rows(parts[0])
             else:
                 self._x = None
         else:
-            self._x = _resident.get(config.x_cpu) if config.x_cpu is not None and config.x_cpu.numel() > 0 else None
+            self._x = _resident.get_rows(config.x_cpu) \
+                if config.x_cpu is not None and config.x_cpu.dim() == 2 and config.x_cpu.numel() > 0 else None
         if self._x is not None and not (self._x.dim() == 2 and self._x.stride(-1) == 1):
             raise RuntimeError("input must be 2D row-major tensor")
         y = config.y
@@ -453,12 +500,14 @@ class Session:
                 xc.comm = comm.handle
                 xc.x_local_dev, xc.x_local_rows = self._x.data_ptr(), self._x.size(0)
                 xc.row_bytes = self._x.size(1) * self._x.element_size()
+                xc.x_local_stride_bytes = _stride_bytes(self._x)
                 if bool(config.use_cache):
                     self._cache_feats = config.cache.device_features()
                     if self._cache_feats.numel():
                         if self._cache_feats.dtype != self._x.dtype or self._cache_feats.size(1) != self._x.size(1):
                             raise RuntimeError("cached_features must match the feature rows in dtype and width")
                         xc.cache_feats_dev, xc.cache_rows = self._cache_feats.data_ptr(), self._cache_feats.size(0)
+                        xc.cache_stride_bytes = _stride_bytes(self._cache_feats)
                 self._xc = xc
                 cfg.exchange = C.pointer(xc)
                 self.native_exchange = True
@@ -474,8 +523,8 @@ class Session:
         self._consumer_stream = None
         self._e_id = torch.empty(0, dtype=torch.int64, device=self._dev)
         # (src pointer, rows, row bytes) of the resident feature / label matrices, built once
-        self._x_args = (C.c_void_p(self._x.data_ptr()), self._x.size(0), self._x.size(1) * self._x.element_size()) \
-            if self._x is not None and self._x.numel() else (None, 0, 0)
+        self._x_args = (C.c_void_p(self._x.data_ptr()), self._x.size(0), self._x.size(1) * self._x.element_size(),
+                        _stride_bytes(self._x)) if self._x is not None and self._x.numel() else (None, 0, 0, 0)
         self._y_args = (C.c_void_p(self._y.data_ptr()), self._y.size(0), self._y.size(1) * self._y.element_size()) \
             if self._y is not None and self._y.numel() else (None, 0, 0)
         self._slice_result = []
@@ -635,11 +684,11 @@ class Session:
     try_get_batch = blocking_get_batch
 
     def _export(self, out, x, y):
-        xa = self._x_args if x is not None and self._x is not None else (None, 0, 0)
+        xa = self._x_args if x is not None and self._x is not None else (None, 0, 0, 0)
         ya = self._y_args if y is not None and self._y is not None else (None, 0, 0)
         nat.check(self._L.spp_session_export(
             self._h, C.byref(out),
-            xa[0], xa[1], xa[2], C.c_void_p(x.data_ptr()) if xa[0] is not None and x.numel() else None,
+            xa[0], xa[1], xa[2], xa[3], C.c_void_p(x.data_ptr()) if xa[0] is not None and x.numel() else None,
             ya[0], ya[1], ya[2], C.c_void_p(y.data_ptr()) if ya[0] is not None and y.numel() else None,
             C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)))
 
@@ -696,7 +745,7 @@ class Session:
             y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
         ya = self._y_args if y is not None else (None, 0, 0)
         nat.check(self._L.spp_session_export(
-            self._h, C.byref(out), None, 0, 0, C.c_void_p(x.data_ptr()) if x.numel() else None,
+            self._h, C.byref(out), None, 0, 0, 0, C.c_void_p(x.data_ptr()) if x.numel() else None,
             ya[0], ya[1], ya[2], C.c_void_p(y.data_ptr()) if ya[0] is not None and y.numel() else None,
             C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)))
         b = ProtoDistributedBatch()
@@ -763,7 +812,8 @@ class Session:
 
 
 def _resident_concat(x_gpu: torch.Tensor, x_cpu: torch.Tensor) -> torch.Tensor:
-    """All local feature rows in one HBM tensor: rows [0, |x_gpu|) then the former host rows."""
+    """All local feature rows in one HBM table (rows padded as in _ResidentCache.get_rows):
+    rows [0, |x_gpu|) then the former host rows."""
     key_t = x_cpu
     dev = _device()
     key = ("cat", x_gpu.data_ptr(), x_cpu.data_ptr(), tuple(x_gpu.shape), tuple(x_cpu.shape), dev.index)
@@ -771,7 +821,12 @@ def _resident_concat(x_gpu: torch.Tensor, x_cpu: torch.Tensor) -> torch.Tensor:
         hit = _resident._d.get(key)
         if hit is not None and hit[0] is key_t:
             return hit[1]
-        r = torch.cat([x_gpu.to(dev), x_cpu.to(dev)], dim=0).contiguous()
+        n0, n1, F = x_gpu.size(0), x_cpu.size(0), x_gpu.size(1)
+        se = _row_stride_elems(F, x_gpu.element_size())
+        buf = torch.empty((n0 + n1, se), dtype=x_gpu.dtype, device=dev)
+        r = buf[:, :F]
+        r[:n0].copy_(x_gpu)
+        r[n0:].copy_(x_cpu)
         _resident._d[key] = (key_t, r)
         return r
 

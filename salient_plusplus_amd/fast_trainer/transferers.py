@@ -66,10 +66,16 @@ class _HipFeatureOps:
     def _stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    @staticmethod
+    def _row_stride(t):
+        """bytes between rows (the resident tables are padded to the HBM fetch granule); 0 = dense"""
+        return int(t.stride(0)) * t.element_size() if t is not None and t.dim() == 2 and t.size(0) > 1 else 0
+
     def gather_rows(self, x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         out = torch.empty((idx.numel(), x.size(1)), dtype=x.dtype, device=x.device)
-        self.nat.check(self.L.spp_gather_rows(self._p(x), x.size(0), x.size(1) * x.element_size(), self._p(idx), 8,
-                                              idx.numel(), idx.numel(), self._p(out), self._stream()))
+        self.nat.check(self.L.spp_gather_rows_strided(self._p(x), x.size(0), x.size(1) * x.element_size(),
+                                                      self._row_stride(x), self._p(idx), 8, idx.numel(), idx.numel(),
+                                                      self._p(out), self._stream()))
         return out
 
     def assemble(self, n_id, perm, seg_start: List[int], P: int, rank: int, rank_offset: int, x_local, recv,
@@ -80,7 +86,7 @@ class _HipFeatureOps:
         self.nat.check(self.L.spp_assemble_features(
             self._p(n_id), self._p(perm), U, seg, P, rank, rank_offset, self._p(x_local), x_local.size(0),
             self._p(recv), self._p(cache_feats), self._p(cached_nids), x_local.size(1) * x_local.element_size(),
-            self._p(out), self._stream()))
+            self._row_stride(x_local), self._row_stride(cache_feats), self._p(out), self._stream()))
         return out
 
 

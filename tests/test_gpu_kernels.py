@@ -66,6 +66,27 @@ def test_gather_rows(lib, dtype, F, idx_bytes):
     assert (got[7:] == 0xAB).all()
 
 
+@pytest.mark.parametrize("row_bytes,stride", [(200, 256), (200, 200), (14, 16), (344, 384), (6, 10), (1536, 1664)])
+def test_gather_rows_strided_source(lib, row_bytes, stride):
+    """Padded resident feature table: rows `stride` bytes apart, dense output; padding bytes are never
+    copied (they hold a poison value)."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(row_bytes)
+    n_src, n_idx = 4000, 2777
+    table = np.full((n_src, stride), 0xEE, dtype=np.uint8)
+    table[:, :row_bytes] = rng.integers(0, 256, size=(n_src, row_bytes), dtype=np.uint8)
+    idx = rng.integers(0, n_src, size=n_idx).astype(np.int64)
+    want = orc.serial_index(np.ascontiguousarray(table[:, :row_bytes]), idx)
+    d_src, d_idx = dev(table), dev(idx)
+    out = torch.zeros((n_idx, row_bytes), dtype=torch.uint8, device="cuda")
+    check(lib, lib.spp_gather_rows_strided(P(d_src), n_src, row_bytes, stride, P(d_idx), 8, n_idx, n_idx, P(out), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    # a stride smaller than the row is refused
+    assert lib.spp_gather_rows_strided(P(d_src), n_src, row_bytes, row_bytes - 1, P(d_idx), 8, n_idx, n_idx, P(out),
+                                       None) != 0
+
+
 def test_to_row_major(lib):
     from oracle import oracle as orc
     rng = np.random.default_rng(0)
