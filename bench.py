@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true",
                     help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--split-seeds", action="store_true",
+                    help="N>1: give each rank 1/N of the training ids per epoch (the reference's DistributedShuffler) "
+                         "instead of a full-length permutation of its own")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -275,13 +278,23 @@ def main():
             else torch.empty(0, dtype=torch.int64, device=dev)
         cache = fs.Cache(rank, world, cached_vertices, wl.x[cached_vertices].contiguous()) if n_cache > 0 \
             else fs.Cache()
-        # seeds: global seeded shuffle, contiguous slice per rank (shufflers.py:32-45); every rank runs
-        # the same number of batches of `bs` seeds (force_exact_num_batches keeps the all_to_alls aligned)
-        shuffler = DistributedShuffler(wl.train_idx, world)
-        n_local = wl.train_idx.numel() // world
+        # Seeds.  Weak scaling keeps the per-GPU work fixed: every rank runs the N=1 epoch (n_train // bs
+        # batches) on its own seeded permutation of the training ids, so epoch boundaries (a pipeline
+        # refill each) are as frequent as at N=1.  --split-seeds gives the reference's split instead
+        # (shufflers.py:32-45: one global permutation, contiguous 1/N slice per rank, epochs N times
+        # shorter).  Either way every rank runs the same number of batches of `bs` seeds
+        # (force_exact_num_batches keeps the exchanges aligned).
+        if a.split_seeds:
+            shuffler = DistributedShuffler(wl.train_idx, world)
+            get_idx = lambda: shuffler.get_idx(rank)                       # noqa: E731
+            n_local = wl.train_idx.numel() // world
+        else:
+            shuffler = Shuffler(wl.train_idx, Shuffler.DEFAULT_INITIAL_SEED + 7919 * rank)
+            get_idx = shuffler.get_idx
+            n_local = wl.train_idx.numel()
         cfg = FastSamplerConfig(
             x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=x_local, y=y2, rowptr=wl.rowptr, col=wl.col,
-            idx=shuffler.get_idx(rank), batch_size=bs, sizes=sizes, skip_nonfull_batch=False, pin_memory=False,
+            idx=get_idx(), batch_size=bs, sizes=sizes, skip_nonfull_batch=False, pin_memory=False,
             distributed=True, partition_book=pb, cache=cache, force_exact_num_batches=True,
             exact_num_batches=max(1, n_local // bs), count_remote_frequency=False, use_cache=n_cache > 0)
         sampler = FastSampler(4, a.slots, cfg)
@@ -289,7 +302,7 @@ def main():
         def make_iter(idx):
             sampler.idx = idx
             return DeviceDistributedPrefetcher([dev], iter(sampler), pipeline_on=True)
-        feeder = EpochFeeder(make_iter, shuffler, lambda: shuffler.get_idx(rank))
+        feeder = EpochFeeder(make_iter, shuffler, get_idx)
         # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
         # all of them fall back to the torch.distributed transport together
         try:
@@ -305,7 +318,7 @@ def main():
             os.environ["SPP_DIST_TRANSPORT"] = "torch"
             native = False
         parallelism = f"dp{world}: features range-partitioned {world}-way, VIP(degree) cache " \
-                      f"{a.cache_frac:.0%} of N/P rows, " + \
+                      f"{a.cache_frac:.0%} of N/P rows, {max(1, n_local // bs)} batches per rank and epoch, " + \
                       ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
                        if native else "torch.distributed all_to_all_single per batch")
 

@@ -53,6 +53,13 @@ def main():
             for name, ind, eb in (("i64", idx, 8), ("i32", idx32, 4)):
                 ms = timeit(lambda: L.spp_gather_rows(P(wl.x), N, F * 2, P(ind), eb, U, U, P(out), st))
                 print(f"gather U={U} F={F} idx={name}: {ms*1e3:.1f} us  alg {(U*(4*F+8))/ms/1e6:.1f} GB/s", flush=True)
+            # the resident layout: rows padded to the 128-B fetch granule
+            pad = torch.empty((N, 128), dtype=wl.x.dtype, device=dev)
+            pad[:, :F].copy_(wl.x)
+            ms = timeit(lambda: L.spp_gather_rows_strided(P(pad), N, F * 2, 256, P(idx32), 4, U, U, P(out), st))
+            print(f"gather U={U} F={F} idx=i32 stride=256: {ms*1e3:.1f} us  alg {(U*(4*F+8))/ms/1e6:.1f} GB/s",
+                  flush=True)
+            del pad
             ms = timeit(lambda: torch.index_select(wl.x, 0, idx))
             print(f"torch.index_select U={U}: {ms*1e3:.1f} us  alg {(U*(4*F+8))/ms/1e6:.1f} GB/s", flush=True)
     if "sample" in what:
