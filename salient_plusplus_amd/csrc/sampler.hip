@@ -911,6 +911,7 @@ struct spp_sampler {
   SlotState* h_states = nullptr;     // pinned mirror
   int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
+  XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
 };
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -1118,6 +1119,12 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   if (s->deliver_stream) (void)hipStreamDestroy(s->deliver_stream);
   for (auto st : s->work_streams)
     if (st) (void)hipStreamDestroy(st);
+  for (auto& xb : s->xbuf) {
+    if (xb.send_ids) (void)hipFree(xb.send_ids);
+    if (xb.recv_ids) (void)hipFree(xb.recv_ids);
+    if (xb.send_rows) (void)hipFree(xb.send_rows);
+    if (xb.recv_rows) (void)hipFree(xb.recv_rows);
+  }
   for (void* a : s->allocs) (void)hipFree(a);
   delete s;
 }
@@ -1439,6 +1446,20 @@ spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const 
   hipLaunchKernelGGL(k_pack_remote_ids, dim3(gx, (unsigned)n), dim3(kNT), 0, st, s->d_slots, first_slot, s->part.P,
                      s->part.rank, pack_base_dev, out_dev);
   SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+XBuf* sampler_xbuf(spp_sampler* s, int set) { return &s->xbuf[set % kMaxWorkStreams]; }
+
+spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes) {
+  if (need <= *cap) return SPP_OK;
+  const int64_t ncap = std::max(need + need / 4, *cap * 2);
+  void* v = nullptr;
+  SPP_HIP_TRY(hipMalloc(&v, (size_t)(ncap * unit_bytes)));
+  if (*buf) s->allocs.push_back(*buf);  // released by spp_sampler_destroy
+  *buf = v;
+  *cap = ncap;
+  s->bytes += (ncap) * unit_bytes;
   return SPP_OK;
 }
 

@@ -57,6 +57,23 @@ void sampler_slot_parts(const spp_sampler* s, int slot, SlotParts* out);
 // (m != rank).  pack_base_dev: int64[n*P] in HBM.
 spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const int64_t* pack_base_dev,
                                    int32_t* out_dev, hipStream_t st);
+// Growable exchange buffers of one slot-set.  They belong to the sampler so that they outlive the
+// per-epoch Sessions of a pooled sampler (growing them costs hipMallocs of hundreds of MB).
+struct XBuf {
+  int32_t* send_ids = nullptr;  // node ids this rank requests (peer-major, then batch)
+  int64_t send_ids_cap = 0;
+  int32_t* recv_ids = nullptr;  // node ids the peers request from this rank (peer-major, then batch)
+  int64_t recv_ids_cap = 0;
+  char* send_rows = nullptr;    // their rows, same order
+  int64_t send_rows_cap = 0;    // rows
+  char* recv_rows = nullptr;    // rows received for this rank's batches (peer-major, then batch)
+  int64_t recv_rows_cap = 0;    // rows
+  int64_t row_bytes = 0;        // row size the row buffers were sized for
+};
+XBuf* sampler_xbuf(spp_sampler* s, int set);
+// grow *buf (capacity *cap, in units of unit_bytes) to at least `need`; the outgrown buffer is kept
+// until the sampler is destroyed (kernels in flight may still read it)
+spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes);
 // completion event of the group `slot` belongs to (NULL when nothing was sampled into it)
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot);
 

@@ -68,14 +68,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __res
 struct XSet {
   int64_t* cnt_dev = nullptr;   // [G*P] this rank's request counts, [G*P] pack_base, [world*G*P] everybody's counts
   int64_t* cnt_host = nullptr;  // pinned mirror, same layout
-  int32_t* send_ids = nullptr;  // node ids this rank requests (peer-major, then batch)
-  int64_t send_ids_cap = 0;
-  int32_t* recv_ids = nullptr;  // node ids the peers request from this rank (peer-major, then batch)
-  int64_t recv_ids_cap = 0;
-  char* send_rows = nullptr;    // their rows, same order
-  int64_t send_rows_cap = 0;    // rows
-  char* recv_rows = nullptr;    // rows received for this rank's batches (peer-major, then batch)
-  int64_t recv_rows_cap = 0;    // rows
+  XBuf* b = nullptr;            // growable id / row buffers, owned by the sampler (outlive the Session)
   hipEvent_t cnt_ready = nullptr;
   hipEvent_t rows_done = nullptr;
   bool rows_recorded = false;
@@ -119,7 +112,6 @@ struct spp_session {
   spp_status exchange_rc = SPP_OK;
   std::string exchange_err;
   std::vector<XSet> xsets;
-  std::vector<void*> retired;            // outgrown buffers, released at destroy
   std::atomic<int64_t> sent_bytes{0}, recv_bytes{0};
 };
 
@@ -247,17 +239,6 @@ static spp_status wait_group_launched(spp_session* s, int64_t g) {
 }
 
 // ---- native exchange -----------------------------------------------------------------------------
-static spp_status grow(spp_session* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes) {
-  if (need <= *cap) return SPP_OK;
-  const int64_t ncap = std::max(need + need / 4, *cap * 2);
-  void* v = nullptr;
-  SPP_HIP_TRY(hipMalloc(&v, (size_t)(ncap * unit_bytes)));
-  if (*buf) s->retired.push_back(*buf);  // may still be read by kernels in flight
-  *buf = v;
-  *cap = ncap;
-  return SPP_OK;
-}
-
 static spp_status launch_serve(spp_session* s, const int32_t* ids, int64_t n, char* out, hipStream_t st) {
   if (n <= 0) return SPP_OK;
   const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n, s->xcfg.x_local_stride_bytes);
@@ -326,9 +307,15 @@ static spp_status exchange_group(spp_session* s, int64_t g) {
   SPP_HIP_TRY(hipMemcpyAsync(all_host, all_dev, ge * 8 * (size_t)P, hipMemcpyDeviceToHost, st));
   SPP_HIP_TRY(hipEventRecord(x.cnt_ready, st));
   // meanwhile: regroup the requested ids peer-major (needs only this rank's counts)
-  SPP_TRY(grow(s, (void**)&x.send_ids, &x.send_ids_cap, total_in, 4));
-  SPP_TRY(grow(s, (void**)&x.recv_rows, &x.recv_rows_cap, total_in, rb));
-  if (total_in > 0) SPP_TRY(sampler_pack_remote_ids(s->sampler, set * G, n, x.cnt_dev + ge, x.send_ids, st));
+  XBuf& xb = *x.b;
+  if (xb.row_bytes != rb) {  // the sampler was last used with another feature width: capacities are in rows
+    xb.send_rows_cap = xb.send_rows_cap * xb.row_bytes / rb;
+    xb.recv_rows_cap = xb.recv_rows_cap * xb.row_bytes / rb;
+    xb.row_bytes = rb;
+  }
+  SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.send_ids, &xb.send_ids_cap, total_in, 4));
+  SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.recv_rows, &xb.recv_rows_cap, total_in, rb));
+  if (total_in > 0) SPP_TRY(sampler_pack_remote_ids(s->sampler, set * G, n, x.cnt_dev + ge, xb.send_ids, st));
   SPP_HIP_TRY(hipEventSynchronize(x.cnt_ready));
   // rows peer m wants from this rank (all batches of the group, in batch order)
   int64_t serve_for[SPP_MAX_PARTS], out_base[SPP_MAX_PARTS];
@@ -340,25 +327,25 @@ static spp_status exchange_group(spp_session* s, int64_t g) {
     for (int i = 0; i < G; ++i) serve_for[m] += all_host[((size_t)m * G + i) * P + R];
     total_req += serve_for[m];
   }
-  SPP_TRY(grow(s, (void**)&x.recv_ids, &x.recv_ids_cap, total_req, 4));
-  SPP_TRY(grow(s, (void**)&x.send_rows, &x.send_rows_cap, total_req, rb));
+  SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.recv_ids, &xb.recv_ids_cap, total_req, 4));
+  SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.send_rows, &xb.send_rows_cap, total_req, rb));
 
   // C2: node ids, int32 -- one send and one receive per peer
   SPP_TRY(tr->group_begin());
   for (int m = 0; m < P; ++m) {
     if (m == R) continue;
-    if (want_from[m] > 0) SPP_TRY(tr->send(x.send_ids + in_base[m], (size_t)want_from[m] * 4, m, st));
-    if (serve_for[m] > 0) SPP_TRY(tr->recv(x.recv_ids + out_base[m], (size_t)serve_for[m] * 4, m, st));
+    if (want_from[m] > 0) SPP_TRY(tr->send(xb.send_ids + in_base[m], (size_t)want_from[m] * 4, m, st));
+    if (serve_for[m] > 0) SPP_TRY(tr->recv(xb.recv_ids + out_base[m], (size_t)serve_for[m] * 4, m, st));
   }
   SPP_TRY(tr->group_end(st));
   // K5: one gather of every requested row
-  SPP_TRY(launch_serve(s, x.recv_ids, total_req, x.send_rows, st));
+  SPP_TRY(launch_serve(s, xb.recv_ids, total_req, xb.send_rows, st));
   // C3: the rows, again one send and one receive per peer
   SPP_TRY(tr->group_begin());
   for (int m = 0; m < P; ++m) {
     if (m == R) continue;
-    if (serve_for[m] > 0) SPP_TRY(tr->send(x.send_rows + out_base[m] * rb, (size_t)(serve_for[m] * rb), m, st));
-    if (want_from[m] > 0) SPP_TRY(tr->recv(x.recv_rows + in_base[m] * rb, (size_t)(want_from[m] * rb), m, st));
+    if (serve_for[m] > 0) SPP_TRY(tr->send(xb.send_rows + out_base[m] * rb, (size_t)(serve_for[m] * rb), m, st));
+    if (want_from[m] > 0) SPP_TRY(tr->recv(xb.recv_rows + in_base[m] * rb, (size_t)(want_from[m] * rb), m, st));
   }
   SPP_TRY(tr->group_end(st));
   const size_t cnt_elems = ge;
@@ -428,6 +415,7 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   SPP_HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
   s->xsets.resize((size_t)s->num_sets);
   const size_t cnt_elems = (size_t)s->G * (size_t)s->P;
+  for (size_t k = 0; k < s->xsets.size(); ++k) s->xsets[k].b = sampler_xbuf(s->sampler, (int)k);
   for (auto& x : s->xsets) {
     SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_elems * 8 * (size_t)(s->P + 2)));
     SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_elems * 8 * (size_t)(s->P + 2), hipHostMallocDefault));
@@ -443,14 +431,9 @@ static void exchange_teardown(spp_session* s) {
   for (auto& x : s->xsets) {
     if (x.cnt_dev) (void)hipFree(x.cnt_dev);
     if (x.cnt_host) (void)hipHostFree(x.cnt_host);
-    if (x.send_ids) (void)hipFree(x.send_ids);
-    if (x.recv_ids) (void)hipFree(x.recv_ids);
-    if (x.send_rows) (void)hipFree(x.send_rows);
-    if (x.recv_rows) (void)hipFree(x.recv_rows);
     if (x.cnt_ready) (void)hipEventDestroy(x.cnt_ready);
     if (x.rows_done) (void)hipEventDestroy(x.rows_done);
   }
-  for (void* v : s->retired) (void)hipFree(v);
   if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
 }
 
@@ -570,6 +553,10 @@ extern "C" void spp_session_destroy(spp_session* s) {
   exchange_teardown(s);
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
+  // the consumer's last deliveries still read the slots and the exchange buffers: a (pooled) sampler
+  // must be quiescent before another Session samples into it
+  for (size_t k = 0; k < s->export_done.size(); ++k)
+    if (s->export_done[k] && s->export_recorded[k]) (void)hipEventSynchronize(s->export_done[k]);
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
   for (auto ev : s->export_done)
     if (ev) (void)hipEventDestroy(ev);
@@ -657,7 +644,7 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
     SPP_HIP_TRY(hipStreamWaitEvent(as_stream(stream), x.rows_done, 0));
     AssembleSrc src{};
     src.x_local = static_cast<const char*>(s->xcfg.x_local_dev);
-    src.recv = x.recv_rows;
+    src.recv = x.b->recv_rows;
     src.cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
     src.x_local_stride = s->xcfg.x_local_stride_bytes;
     src.cache_stride = s->xcfg.cache_stride_bytes;
