@@ -342,6 +342,18 @@ typedef struct spp_exchange_cfg {
 /* bytes this rank sent / received through the exchange so far (ids + rows + counts) */
 spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes);
 
+/* ------------------------------------------------------------------------- *
+ * f1  VIP analytic model (driver/drivers/ddp.py:135-239 get_frequency_tensors_fast): per vertex,
+ *     the probability of being touched by one mini-batch of `batch_size` seeds drawn from
+ *     train_idx, propagated over `fanouts` (in the order given, as the reference iterates them).
+ *     float64.  out_dev: double[num_nodes]; workspace_dev: double[3*num_nodes].
+ *     create_vip_cache (ddp.py:417-570) ranks the remote vertices by it.
+ * ------------------------------------------------------------------------- */
+spp_status spp_vip_frequencies(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_nodes,
+                               const int64_t* train_idx_dev, int64_t n_train, int64_t batch_size,
+                               const int64_t* fanouts_host, int32_t num_hops, double* out_dev,
+                               double* workspace_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,3 +281,34 @@ def epoch_run(rowptr, col, x: Optional[np.ndarray], y: Optional[np.ndarray], idx
                              _ptr(ranges), ranges.shape[0], _ptr(sz), sz.shape[0], num_threads, C.byref(st))
     assert rc == 0
     return st
+
+
+# ---- f1: VIP analytic model (numpy restatement; PARITY UNPINNED) -----------------------------------
+def vip_frequencies(rowptr, col, train_idx, fanouts: Sequence[int], batch_size: int) -> np.ndarray:
+    """driver/drivers/ddp.py:135-239 get_frequency_tensors_fast, float64, the Taylor form the
+    reference ships: p0 = batch_size/|train| on the training ids (:154-157); per fanout (in list
+    order, :187): res = segment_csr(min(1, fanout/deg)[col] * p[col], rowptr, 'add') (:222-224),
+    p_next = 1 - exp(-res) (:226); total = 1 - prod(1 - p_h) (:231-235).  The reference's chunking
+    of the CSR (:161-185) only bounds device memory and does not change the values.
+
+    Parity unpinned: the reference function needs torch_scatter / torch_sparse and a partitioned
+    OGB dataset object, neither of which exists in this image, so it cannot be run here; this
+    restatement is checked against a hand-computed case (tests/test_oracle_golden.py)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    n = rowptr.shape[0] - 1
+    deg = (rowptr[1:] - rowptr[:-1]).astype(np.float64)
+    p = np.zeros(n, dtype=np.float64)
+    tr = np.asarray(train_idx, dtype=np.int64)
+    p[tr] = (batch_size * 1.0) / tr.shape[0]
+    seg = np.repeat(np.arange(n, dtype=np.int64), rowptr[1:] - rowptr[:-1])
+    total = np.ones(n, dtype=np.float64)
+    for f in fanouts:
+        with np.errstate(divide="ignore"):
+            w = np.minimum(np.ones_like(deg), f / deg)
+        weighted = w[col] * p[col]
+        res = np.zeros(n, dtype=np.float64)
+        np.add.at(res, seg, weighted)
+        p = 1 - np.exp(-res)
+        total = total * (1 - p)
+    return 1 - total
