@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true",
                     help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--cache-strategy", default="vip", choices=["vip", "degree", "degree-desc"],
+                    help="N>1: ranking of the remote vertices for the feature cache (ddp.py:425-492)")
     ap.add_argument("--split-seeds", action="store_true",
                     help="N>1: give each rank 1/N of the training ids per epoch (the reference's DistributedShuffler) "
                          "instead of a full-length permutation of its own")
@@ -219,6 +221,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X data path has no CPU fallback")
+    if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
+        local_rank = 0                      # all ranks share the one GPU (development aid, see below)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or a.force_distributed
@@ -227,7 +231,26 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
+            # Development aid: several ranks on ONE GPU (RCCL refuses that) -- gloo with host-staged
+            # all_to_all_single, hence the torch.distributed transport; exercises this script's N>1
+            # code path, not a performance configuration.
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            real_a2a = dist.all_to_all_single
+
+            def staged(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+                o = torch.empty(output.shape, dtype=output.dtype)
+                real_a2a(o, input.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes,
+                         group=group)
+                output.copy_(o)
+
+                class _Done:
+                    def wait(self):
+                        return True
+                return _Done() if async_op else None
+            dist.all_to_all_single = staged
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from salient_plusplus_amd import _native as nat
     from salient_plusplus_amd import fast_sampler as fs
@@ -269,15 +292,22 @@ def main():
         lo, hi = int(offsets[rank]), int(offsets[rank + 1])
         x_local = wl.x[lo:hi].contiguous()
         pb = fs.RangePartitionBook(rank, world, offsets)
-        # VIP proxy: the highest-degree remote vertices (cache_strategy "degree"), alpha * N / P rows
-        deg = wl.rowptr[1:] - wl.rowptr[:-1]
-        deg_remote = deg.clone()
-        deg_remote[lo:hi] = -1
+        # VIP cache (ddp.py:417-570): the remote vertices most likely to be touched by this rank's
+        # mini-batches (analytic model, ddp.py:135-239, on the GPU), alpha * N / P rows fetched from
+        # their owners once.  --cache-strategy degree-desc keeps the earlier top-degree proxy.
+        from salient_plusplus_amd.fast_trainer.vip_cache import create_vip_cache, fetch_cache_rows
         n_cache = int(a.cache_frac * N / world) if world > 1 else 0
-        cached_vertices = torch.topk(deg_remote, n_cache).indices.sort().values if n_cache > 0 \
-            else torch.empty(0, dtype=torch.int64, device=dev)
-        cache = fs.Cache(rank, world, cached_vertices, wl.x[cached_vertices].contiguous()) if n_cache > 0 \
-            else fs.Cache()
+        if n_cache > 0 and a.cache_strategy == "degree-desc":
+            deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
+            deg_remote[lo:hi] = -1
+            cv, cf = fetch_cache_rows(pb, torch.topk(deg_remote, n_cache).indices.sort().values, x_local)
+            cache = fs.Cache(rank, world, cv, cf)
+        elif n_cache > 0:
+            cache = create_vip_cache(pb, N, x_local, a.cache_frac * 100.0, a.cache_strategy, rowptr=wl.rowptr,
+                                     col=wl.col, train_idx=wl.train_idx, fanouts=sizes, batch_size=bs)
+            n_cache = int(cache.cached_vertices.numel())
+        else:
+            cache = fs.Cache()
         # Seeds.  Weak scaling keeps the per-GPU work fixed: every rank runs the N=1 epoch (n_train // bs
         # batches) on its own seeded permutation of the training ids, so epoch boundaries (a pipeline
         # refill each) are as frequent as at N=1.  --split-seeds gives the reference's split instead
@@ -317,8 +347,8 @@ def main():
                 print(f"[bench] native exchange unavailable: {native_err}", file=sys.stderr, flush=True)
             os.environ["SPP_DIST_TRANSPORT"] = "torch"
             native = False
-        parallelism = f"dp{world}: features range-partitioned {world}-way, VIP(degree) cache " \
-                      f"{a.cache_frac:.0%} of N/P rows, {max(1, n_local // bs)} batches per rank and epoch, " + \
+        parallelism = f"dp{world}: features range-partitioned {world}-way, {a.cache_strategy} cache " \
+                      f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {max(1, n_local // bs)} batches per rank and epoch, " + \
                       ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
                        if native else "torch.distributed all_to_all_single per batch")
 
