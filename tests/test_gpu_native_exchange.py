@@ -237,3 +237,68 @@ def test_native_exchange_products_scale_two_ranks():
     # what rank 0 sent in rows is what rank 1 received, and vice versa (ids + rows + counts)
     assert out[0][0] > 1e8 and out[1][0] > 1e8
     fs.clear_resident_cache()
+
+
+def test_partitioned_dataset_from_disk_through_exchange(tmp_path):
+    """f1 -> f2 -> exchange: VIP probabilities order the vertices inside each partition, the dataset
+    is written in the reference's partitioned layout, every rank loads its own x<r>.pt and the
+    native exchange reassembles exactly the rows of the reordered full table."""
+    from oracle import oracle as orc
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.dataset import DisjointPartFeatReorderedDataset as D, FastDataset
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+    from salient_plusplus_amd.fast_trainer.vip_cache import vip_frequencies
+    g = _graph()
+    T = torch.from_numpy
+    n = g["rowptr"].shape[0] - 1
+    P, bs, nb = 2, 16, 5
+    rng = np.random.default_rng(5)
+    split = {"train": T(g["idx"].copy()), "valid": T(np.arange(10)), "test": T(np.arange(10, 20))}
+    ds = FastDataset.from_tensors("toy", T(g["x"].astype(np.float32)), T(g["y"]), T(g["rowptr"]), T(g["col"]), split, 8)
+    labels = T(rng.integers(0, P, size=n))
+    prob = vip_frequencies(ds.rowptr, ds.col, split["train"], SIZES, bs).cpu()
+    root = D.reorder_and_save(ds, labels, prob, tmp_path).parent
+    parts = [D.from_path(root, "toy", r) for r in range(P)]
+    x_full = torch.cat([p.x for p in parts]).numpy()
+    rowptr, col = parts[0].rowptr.numpy(), parts[0].col.numpy()
+    comms = fs.NativeComm.local(P)
+    errors = []
+
+    def run(r):
+        it = None
+        try:
+            torch.cuda.set_device(0)
+            fs.set_native_comm(comms[r])
+            d = parts[r]
+            idx = d.split_idx_parts[r]["train"][:nb * bs]
+            cfg = FastSamplerConfig(
+                x_cpu=torch.empty((0, d.num_features), dtype=d.x.dtype), x_gpu=d.x.cuda(), y=d.y.unsqueeze(-1),
+                rowptr=d.rowptr, col=d.col, idx=idx, batch_size=bs, sizes=SIZES, skip_nonfull_batch=False,
+                pin_memory=False, distributed=True, partition_book=d.get_RangePartitionBook(), cache=fs.Cache(),
+                force_exact_num_batches=True, exact_num_batches=nb, count_remote_frequency=False, use_cache=False)
+            ranges = orc.batch_ranges(idx.numel(), bs, False, True, nb)
+            it = iter(FastSampler(2, 8, cfg))
+            assert it.session.native_exchange
+            for k, proto in enumerate(it):
+                m = orc.sample_batch(rowptr, col, idx.numpy(), int(ranges[k][0]), int(ranges[k][1]), SIZES)
+                np.testing.assert_array_equal(proto.n_id.cpu().numpy(), m.n_id)
+                np.testing.assert_array_equal(proto.x.cpu().numpy().view(np.uint16), x_full[m.n_id].view(np.uint16))
+            it.session.close()
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+            errors.append(f"rank {r}: {e}\n{traceback.format_exc()}")
+            if it is not None:
+                it.session.close()
+            comms[r].close()
+        finally:
+            fs.set_native_comm(None)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not any(t.is_alive() for t in ts)
