@@ -144,6 +144,11 @@ class EpochFeeder:
         self.devit = self.make_iter(self.get_idx())
         self.epoch += 1
 
+    def quiesce(self):
+        q = getattr(self.devit, "quiesce", None)
+        if q is not None:
+            q()
+
     def next(self):
         if self.devit is None:
             self._new_epoch()
@@ -357,6 +362,7 @@ def main():
         feeder.next()
     torch.cuda.synchronize()
     if distributed:
+        feeder.quiesce()      # nothing of the exchange's communicator in flight while the barrier's kernels run
         dist.barrier()
     torch.cuda.synchronize()
     L.spp_profile_enable(1)
@@ -368,6 +374,7 @@ def main():
         nodes += b.x.size(0)
     torch.cuda.synchronize()
     if distributed:
+        feeder.quiesce()
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -339,6 +339,12 @@ typedef struct spp_exchange_cfg {
   int64_t cache_stride_bytes;
 } spp_exchange_cfg;
 
+/* BLOCKING: returns when the session's threads have issued everything they can without further
+ * consumption (sampling chains and exchanges of the slot-sets in flight) and that work has completed
+ * on the GPU.  Call it on every rank before issuing collectives of ANOTHER communicator (e.g. a
+ * torch.distributed barrier): kernels of two communicators that wait for their peers must not be
+ * queued behind one another in opposite orders on different ranks. */
+spp_status spp_session_quiesce(spp_session* s);
 /* bytes this rank sent / received through the exchange so far (ids + rows + counts) */
 spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes);
 

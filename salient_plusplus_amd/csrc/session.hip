@@ -666,3 +666,22 @@ extern "C" spp_status spp_session_exchange_stats(const spp_session* s, int64_t* 
   if (recv_bytes) *recv_bytes = s->recv_bytes.load();
   return SPP_OK;
 }
+
+extern "C" spp_status spp_session_quiesce(spp_session* s) {
+  SPP_REQUIRE(s, "spp_session_quiesce: NULL session");
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [s] {
+      const int64_t target = std::min<int64_t>(s->num_groups, s->groups_consumed + s->num_sets);
+      const bool launcher_idle = s->launch_rc != SPP_OK || s->chain_launched >= target;
+      const bool exchanger_idle = !s->tr || s->exchange_rc != SPP_OK || s->launch_rc != SPP_OK ||
+                                  s->exchange_launched >= target;
+      return launcher_idle && exchanger_idle;
+    });
+  }
+  SPP_HIP_TRY(hipSetDevice(s->cfg.device));
+  for (auto st : s->streams)
+    if (st) SPP_HIP_TRY(hipStreamSynchronize(st));
+  if (s->comm_stream) SPP_HIP_TRY(hipStreamSynchronize(s->comm_stream));
+  return SPP_OK;
+}

@@ -764,6 +764,12 @@ class Session:
             self._count_remote(b.partition_nids, rank)
         return b
 
+    def quiesce(self):
+        """Block until the session has nothing more to issue without further consumption and its GPU
+        work is done (call on every rank before collectives of another communicator)."""
+        if self._h is not None:
+            nat.check(self._L.spp_session_quiesce(self._h))
+
     def exchange_bytes(self):
         """(sent, received) bytes of the native exchange so far."""
         a, b = C.c_int64(0), C.c_int64(0)

@@ -314,6 +314,15 @@ class DeviceDistributedPrefetcher(DeviceIterator):
     def print_stats(self):
         return
 
+    def quiesce(self):
+        """See fast_sampler.Session.quiesce: drain what the native exchange has in flight before the
+        caller issues collectives on its own process group."""
+        q = getattr(self.it.session, "quiesce", None)
+        if q is not None:
+            q()
+        if self.side.cuda:
+            torch.cuda.synchronize()
+
 
 class DevicePrefetcher(DeviceIterator):
     """Single-GPU double buffering (transferers.py:890-970): the next batch is sampled, sliced and

@@ -78,6 +78,8 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
                     np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
                     np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
                 got += 1
+                if got == 2:
+                    pre.quiesce()       # every rank at the same batch: all in-flight exchanges complete
             assert got == nb
             stats[rank] = pre.NUMBER_OF_SENT_BYTES
             it.session.close()
