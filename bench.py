@@ -94,10 +94,16 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=24, warm=4):
-    """ms/step of fwd+bwd+Adam with the data path feeding it, and with one resident batch re-used."""
+def model_step_timing(feeder, F, n_classes, steps=24, warm=4, hip=True):
+    """ms/step of fwd+bwd+Adam with the data path feeding it, and with one resident batch re-used.
+    hip=True: salient_plusplus_amd.models.SAGE (HIP mean aggregation); False: the plain-torch
+    formulation above."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    model = TorchSAGE(F, 256, n_classes).to(dev)
+    if hip:
+        from salient_plusplus_amd.models import SAGE
+        model = SAGE(F, 256, n_classes, 3).to(dev)
+    else:
+        model = TorchSAGE(F, 256, n_classes).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
     def step(b):
@@ -436,12 +442,15 @@ def main():
         }
         if not a.no_model_step and not distributed:
             try:
-                m_only, m_data = model_step_timing(feeder, F, 47)
+                m_only, m_data = model_step_timing(feeder, F, 47, hip=True)
+                t_only, t_data = model_step_timing(feeder, F, 47, hip=False)
                 nb_epoch = wl.train_idx.numel() // bs
                 out["epoch_time_s_with_sage_step"] = nb_epoch * m_data / 1e3
-                out["model_step"] = {"model": "SAGE 3x256 (plain-torch stand-in, fp32, Adam)",
+                out["model_step"] = {"model": "SAGE 3x256 (models.py: HIP mean aggregation + library GEMMs, fp32, Adam)",
                                      "ms_per_step_model_only_resident_batch": m_only,
-                                     "ms_per_step_with_data_path": m_data}
+                                     "ms_per_step_with_data_path": m_data,
+                                     "plain_torch_formulation": {"ms_per_step_model_only_resident_batch": t_only,
+                                                                 "ms_per_step_with_data_path": t_data}}
             except Exception as e:  # noqa: BLE001
                 out["model_step"] = {"error": repr(e)}
         if not a.no_cpu_baseline and not distributed:

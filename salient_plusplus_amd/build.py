@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libspp_hip.so")
-SOURCES = ["api.hip", "mt19937.hip", "gather.hip", "sampler.hip", "partition.hip", "session.hip", "exchange.hip", "vip.hip"]
+SOURCES = ["api.hip", "mt19937.hip", "gather.hip", "sampler.hip", "partition.hip", "session.hip", "exchange.hip", "vip.hip", "aggregate.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-Wall", "-Wno-unused-function"] + os.environ.get("SPP_EXTRA_FLAGS", "").split()

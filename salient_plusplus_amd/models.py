@@ -1,0 +1,106 @@
+"""Model-step fallback for boxes without PyG / torch_sparse: the reference's flagship
+``SAGE`` (driver/models.py:19-56: ``num_layers`` x SAGEConv(bias=False, mean aggregation), ReLU +
+dropout 0.5 between layers, log_softmax) on the MFG's CSR, with the message passing on HIP kernels
+(csrc/aggregate.hip) and the linear layers on the library GEMMs torch dispatches to.
+
+The constructor, ``reset_parameters`` and ``forward(x, adjs)`` follow the reference; ``adjs`` is
+what the data path delivers: ``[(adj_t, e_id, (S, T)), ...]``, outermost hop first."""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as nat
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+
+class _MeanAggregate(torch.autograd.Function):
+    """out[t] = mean_{e in row t} x[col[e]]  (empty rows give 0, as PyG's mean aggregation)."""
+
+    @staticmethod
+    def forward(ctx, x, rowptr, col, num_targets):
+        L = nat.load()
+        nat.require_device()
+        assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.float32)
+        Fdim = x.size(1)
+        out = torch.empty((num_targets, Fdim), dtype=torch.float32, device=x.device)
+        nat.check(L.spp_csr_mean_forward(_p(rowptr), _p(col), num_targets, _p(x), int(x.dtype == torch.float16),
+                                         x.stride(0) if x.size(0) > 1 else Fdim, Fdim, _p(out),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ctx.save_for_backward(rowptr, col)
+        ctx.shape = (x.size(0), Fdim, num_targets)
+        ctx.in_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None
+        rowptr, col = ctx.saved_tensors
+        S, Fdim, T = ctx.shape
+        g = grad_out.contiguous().to(torch.float32)
+        grad_x = torch.zeros((S, Fdim), dtype=torch.float32, device=g.device)
+        nat.check(nat.load().spp_csr_mean_backward(_p(rowptr), _p(col), T, _p(g), Fdim, _p(grad_x),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return grad_x.to(ctx.in_dtype), None, None, None
+
+
+def mean_aggregate(x, rowptr, col, num_targets):
+    return _MeanAggregate.apply(x, rowptr, col, num_targets)
+
+
+def init_weights(m):                                     # driver/models.py:12-16
+    if isinstance(m, torch.nn.Linear):
+        torch.nn.init.xavier_uniform_(m.weight, gain=torch.nn.init.calculate_gain("relu"))
+
+
+class SAGEConv(torch.nn.Module):
+    """torch_geometric.nn.SAGEConv(in, out, aggr='mean', root_weight=True, bias=...) on a bipartite
+    ((x, x_target), adj_t):  lin_l(mean_j x_j) + lin_r(x_target); only lin_l carries the bias."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.lin_l = torch.nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = torch.nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x_pair, adj_t):
+        x, x_target = x_pair
+        rowptr, col, _ = adj_t.csr()
+        agg = mean_aggregate(x, rowptr, col, x_target.size(0))
+        return self.lin_l(agg) + self.lin_r(x_target.to(torch.float32))
+
+
+class SAGE(torch.nn.Module):
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        self.hidden_channels = hidden_channels
+        self.convs = torch.nn.ModuleList()
+        self.convs.append(SAGEConv(in_channels, hidden_channels, bias=False))
+        for _ in range(num_layers - 2):
+            self.convs.append(SAGEConv(hidden_channels, hidden_channels, bias=False))
+        self.convs.append(SAGEConv(hidden_channels, out_channels, bias=False))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+            conv.apply(init_weights)
+
+    def forward(self, x, adjs):
+        # the reference converts the whole feature matrix to fp32 first (models.py:43); the first
+        # aggregation reads the fp16 rows directly instead (exact) and only the targets are converted
+        for i, (adj_t, _e_id, size) in enumerate(adjs):
+            x_target = x[:size[1]]
+            x = self.convs[i]((x, x_target), adj_t)
+            if i != self.num_layers - 1:
+                x = F.relu(x)
+                x = F.dropout(x, p=0.5, training=self.training)
+        return torch.log_softmax(x, dim=-1)
