@@ -1388,7 +1388,7 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
     for (int m = 0; m < s->part.P; ++m) a.recv_base[m] = asrc->recv_base[m];
     SPP_REQUIRE(hs->pcnt[s->part.P] == 0 || asrc->cache, "sampler_deliver: cache hits without cache rows");
   }
-  if (x_src && x_dst && U > 0 && x_row_bytes > 0) {
+  if ((x_src || asrc) && x_dst && U > 0 && x_row_bytes > 0) {  // a rank may own no rows at all (x_local NULL)
     if (x_src_stride <= 0) x_src_stride = x_row_bytes;
     SPP_REQUIRE(x_src_stride >= x_row_bytes, "spp_session_export: source stride %lld smaller than the row (%lld bytes)",
                 (long long)x_src_stride, (long long)x_row_bytes);

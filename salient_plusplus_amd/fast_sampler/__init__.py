@@ -450,7 +450,9 @@ class Session:
             elif len(parts) == 1:
                 self._x = _resident.get_rows(parts[0])
             else:
-                self._x = None
+                # a rank that owns no rows still takes part in the exchange: keep the width and dtype
+                wide = [t for t in (xg, xc) if t is not None and t.dim() == 2 and t.size(1) > 0]
+                self._x = torch.empty((0, wide[0].size(1)), dtype=wide[0].dtype, device=self._dev) if wide else None
         else:
             self._x = _resident.get_rows(config.x_cpu) \
                 if config.x_cpu is not None and config.x_cpu.dim() == 2 and config.x_cpu.numel() > 0 else None

@@ -100,12 +100,16 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
     (3, True, 5, 24, 16),       # three ranks
     (2, True, 37, 4, 32),       # four slot-sets of 8 in flight, ragged tail
     (8, True, 9, 8, 32),        # the scaling bench's rank count
+    (-2, False, 4, 16, 8),      # degenerate book: rank 0 owns every vertex, rank 1 none (all its rows are remote)
 ])
 def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
     from salient_plusplus_amd import fast_sampler as fs
     g = _graph()
     n = g["rowptr"].shape[0] - 1
-    offsets = {2: [0, 1400, n], 3: [0, 900, 2100, n]}.get(P) or [int(v) for v in np.linspace(0, n, P + 1)]
+    if P == -2:
+        P, offsets = 2, [0, n, n]
+    else:
+        offsets = {2: [0, 1400, n], 3: [0, 900, 2100, n]}.get(P) or [int(v) for v in np.linspace(0, n, P + 1)]
     comms = fs.NativeComm.local(P)
     errors, stats = [], {}
     ts = [threading.Thread(target=_run_rank, args=(r, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stats))
@@ -119,7 +123,7 @@ def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
         c.close()
     assert not errors, "\n".join(errors)
     assert not hung, "rank thread hung"
-    assert all(stats[r] > 0 for r in range(P))     # rows really travelled
+    assert all(stats[r] > 0 for r in range(P))     # counts / ids / rows really travelled
 
 
 def test_rccl_world1_comm_and_session():
