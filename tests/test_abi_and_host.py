@@ -67,6 +67,15 @@ def test_product_fails_loudly_without_gpu():
     cfg.batch_size, cfg.sizes = 1, [1]
     with pytest.raises(nat.SppError):
         fs.Session(1, 1, cfg)
+    # the rows either side of the path have no CPU fallback either
+    from salient_plusplus_amd.fast_trainer.vip_cache import vip_frequencies
+    from salient_plusplus_amd.models import mean_aggregate
+    with pytest.raises(nat.SppError):
+        vip_frequencies(cfg.rowptr, cfg.col, cfg.idx, [1], 1)
+    with pytest.raises(nat.SppError):
+        fs.NativeComm.local(2)
+    with pytest.raises((nat.SppError, AssertionError)):
+        mean_aggregate(torch.zeros(2, 4), torch.zeros(2, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 1)
 
 
 def test_product_never_imports_the_oracle():
