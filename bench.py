@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Hot-path benchmark: sampled-edges/s of the mini-batch data pipeline (neighbour sampling ->
-MFG -> feature/label slice -> PreparedBatch in HBM) on the BASELINE.json config that fits one GPU:
-ogbn-products scale (synthetic, seeded), GraphSAGE fanout [15,10,5], batch 1024, all features in HBM.
+MFG -> feature/label slice -> PreparedBatch in HBM) on the dataset BASELINE.json's metric is quoted
+on: ogbn-papers100M scale (synthetic, seeded: 111 M nodes, 3.2 G symmetric nnz, F=128 fp16 -- 56 GB
+of topology + features, which fit one MI355X), GraphSAGE fanout [15,10,5], batch 1024.
+`--workload S-products` runs BASELINE.json's configs[1] instead.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one batch through the hot path.  N == 1: single-GPU iterator (FastSampler +
-DevicePrefetcher).  N > 1: one process per GPU, replicated topology, features range-partitioned
-N ways with a degree-ranked VIP cache of remote rows, cache-miss rows fetched by RCCL
-all_to_all_single (DeviceDistributedPrefetcher); every rank runs K of its own batches (weak
-scaling).  Rank 0 prints ONE JSON line.
+DevicePrefetcher), all features in HBM.  N > 1: one process per GPU, replicated topology, features
+range-partitioned N ways with a VIP cache of remote rows (analytic model, 10 % of N/P), cache-miss
+rows fetched over RCCL/xGMI by the native exchange (DeviceDistributedPrefetcher); every rank runs K
+of its own batches (weak scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -33,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-products"))
+    ap.add_argument("--workload", default=os.environ.get("SPP_BENCH_WORKLOAD", "S-papers"),
+                    help="S-papers (default: the dataset BASELINE.json's metric is quoted on; 56 GB of graph + "
+                         "features fit one MI355X), S-products (configs[1]), S-arxiv, S-tiny")
     ap.add_argument("--slots", type=int, default=0,
                     help="batch slots in flight (0 = 16 single-GPU, 32 distributed: 4 slot-sets of 8)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
@@ -419,13 +423,16 @@ def main():
                 "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
-        pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
-        if not distributed and os.path.exists(pmc_path):
+        for pmc_name in ("r01_gather_pmc_papers.json", "r01_gather_pmc.json"):
+            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+            if distributed or not os.path.exists(pmc_path):
+                continue
             pmc = json.load(open(pmc_path))
             if pmc["shape"]["row_bytes"] == row_bytes:
                 roof["traffic"] = pmc["traffic_bytes_per_row"] * roof["rows_per_launch"]
-                roof["traffic_source"] = "profiles/r01_gather_pmc.json (bytes/row x rows/launch)"
+                roof["traffic_source"] = f"profiles/{pmc_name} (bytes/row x rows/launch)"
                 roof["algorithmic_bytes_per_launch"] = alg_bytes_per_row * roof["rows_per_launch"]
+                break
         out = {
             "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -11,6 +11,8 @@ WORKLOADS = {
     "S-tiny": (20_000, 200_000, 32, 4_096, [15, 10, 5], 256),
     "S-arxiv": (169_343, 1_166_243, 128, 90_941, [15, 10, 5], 1024),
     "S-products": (2_449_029, 61_859_140, 100, 196_615, [15, 10, 5], 1024),
+    # ogbn-papers100M scale: 111 M nodes, ~3.2 G symmetric nnz (col 25.8 GB int64), F=128 fp16 (28.4 GB)
+    "S-papers": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
 }
 
 
@@ -30,12 +32,17 @@ class Workload(NamedTuple):
 
 
 def make_graph(num_nodes: int, num_directed: int, seed: int, device) -> tuple:
-    """endpoints src = perm[floor(N*u^2)], dst = floor(N*v): a few very high degree hubs, long tail."""
+    """endpoints src = perm[floor(N*u^2)], dst = floor(N*v): a few very high degree hubs, long tail.
+
+    The (row, col) keys are sorted and coalesced per ROW RANGE so that no single sort sees 2^31 keys
+    (papers100M scale has 3.2 G of them); with one range this is exactly one global unique()."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     N = num_nodes
     perm = torch.randperm(N, generator=g, device=device)
-    chunks = []
+    n_ranges = max(1, -(-2 * num_directed // (1 << 30)))
+    bounds = torch.tensor([(N * k) // n_ranges for k in range(n_ranges + 1)], device=device, dtype=torch.int64) * N
+    pieces = [[] for _ in range(n_ranges)]
     CH = 1 << 25
     left = num_directed
     while left > 0:
@@ -46,18 +53,31 @@ def make_graph(num_nodes: int, num_directed: int, seed: int, device) -> tuple:
         dst = (v * N).long().clamp_(max=N - 1)
         keep = src != dst
         src, dst = src[keep], dst[keep]
-        chunks.append(src * N + dst)
-        chunks.append(dst * N + src)          # symmetric
+        if n_ranges == 1:
+            pieces[0].append(src * N + dst)
+            pieces[0].append(dst * N + src)          # symmetric
+        else:
+            key = torch.sort(torch.cat([src * N + dst, dst * N + src])).values
+            cut = torch.searchsorted(key, bounds).tolist()
+            for k in range(n_ranges):
+                if cut[k + 1] > cut[k]:
+                    pieces[k].append(key[cut[k]:cut[k + 1]].clone())
+            del key
         left -= m
-    key = torch.cat(chunks)
-    del chunks
-    key = torch.unique(key)                    # sorted + coalesced
-    row = torch.div(key, N, rounding_mode="floor")
-    col = key - row * N
-    del key
-    counts = torch.bincount(row, minlength=N)
+    cols, counts = [], []
+    for k in range(n_ranges):
+        key = torch.unique(torch.cat(pieces[k]))       # sorted + coalesced
+        pieces[k] = None
+        row = torch.div(key, N, rounding_mode="floor")
+        cols.append(key - row * N)
+        lo = (N * k) // n_ranges
+        hi = (N * (k + 1)) // n_ranges
+        counts.append(torch.bincount(row - lo, minlength=hi - lo))
+        del key, row
+    col = torch.cat(cols) if n_ranges > 1 else cols[0]
+    del cols
     rowptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
-    torch.cumsum(counts, 0, out=rowptr[1:])
+    torch.cumsum(torch.cat(counts) if n_ranges > 1 else counts[0], 0, out=rowptr[1:])
     return rowptr, col.contiguous()
 
 
@@ -68,7 +88,11 @@ def make_workload(name: str, seed: int = 1234, device=None) -> Workload:
     rowptr, col = make_graph(N, m, seed, device)
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1)
-    x = torch.randn((N, F), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+    x = torch.empty((N, F), device=device, dtype=torch.float16)
+    step = 1 << 23                                       # chunked: no fp32 copy of a papers-scale matrix
+    for i in range(0, N, step):
+        j = min(N, i + step)
+        x[i:j] = torch.randn((j - i, F), generator=g, device=device, dtype=torch.float32).to(torch.float16)
     y = torch.randint(0, 47, (N,), generator=g, device=device, dtype=torch.int64)
     train_idx = torch.randperm(N, generator=g, device=device)[:n_train].contiguous()
     return Workload(name, rowptr, col, x, y, train_idx, list(fanouts), bs)

@@ -6,6 +6,9 @@ import json
 import sys
 
 fetch_csv, write_csv, stride, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+ROW = int(sys.argv[5]) if len(sys.argv) > 5 else 200            # row bytes
+N = int(sys.argv[6]) if len(sys.argv) > 6 else 770_000          # rows of the measured launch
+TABLE = int(sys.argv[7]) if len(sys.argv) > 7 else 2_449_029
 
 
 def gather_rows(path, counter):
@@ -15,7 +18,7 @@ def gather_rows(path, counter):
     return float(rows[0]["Counter_Value"]), float(rows[1]["Counter_Value"]), rows[1]["Kernel_Name"].split("(")[0]
 
 
-ROW, N_CAL, N = 200, 4_000_000, 770_000
+N_CAL = 4_000_000
 f_cal, f_meas, name = gather_rows(fetch_csv, "FETCH_SIZE")
 w_cal, w_meas, _ = gather_rows(write_csv, "WRITE_SIZE")
 cal_read = N_CAL * (ROW + 4)          # rows + int32 index, every byte once
@@ -28,7 +31,7 @@ alg = 2 * ROW + 8
 doc = {
     "kernel": name.replace("void ", ""),
     "tool": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/pmc_gather.py + tools/pmc_gather_report.py",
-    "shape": {"rows": N, "row_bytes": ROW, "src_stride_bytes": stride, "table_rows": 2449029, "index": "int32 random"},
+    "shape": {"rows": N, "row_bytes": ROW, "src_stride_bytes": stride, "table_rows": TABLE, "index": "int32 random"},
     "calibration": {"rows": N_CAL, "index": "arange over a dense table (every byte once, 800 MB >> Infinity Cache)",
                     "FETCH_SIZE_KB": f_cal, "WRITE_SIZE_KB": w_cal, "fetch_correction": fc, "write_correction": wc,
                     "note": "FETCH_SIZE reads 1/2 of the fetched bytes on gfx950 (MI355X_MICROARCH.md, HBM); "
@@ -38,9 +41,10 @@ doc = {
     "traffic_bytes_per_row": (read + write) / N,
     "algorithmic_bytes_per_row": alg,
     "read_amplification": read / (N * (ROW + 4)),
-    "comment": "rows start on a 128-B fetch granule (resident table padded to 256 B per 200-B row): "
-               "2 granules per row instead of 2.56 for the dense layout (which measured 520 B/row)"
-               if stride == 256 else "dense rows",
+    "comment": ("rows start on a 128-B fetch granule (resident table padded to 256 B per 200-B row): "
+                "2 granules per row instead of 2.56 for the dense layout (which measured 520 B/row)")
+               if (stride == 256 and ROW == 200) else
+               ("256-B rows are exactly two fetch granules" if ROW == 256 else "dense rows"),
 }
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc["corrected_bytes"]), doc["traffic_bytes_per_row"], doc["read_amplification"])
