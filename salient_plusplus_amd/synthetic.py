@@ -16,6 +16,9 @@ WORKLOADS = {
 }
 
 
+MAX_KEYS_PER_SORT = 1 << 30     # torch.unique / CUB take fewer than 2^31 keys per call
+
+
 class Workload(NamedTuple):
     name: str
     rowptr: torch.Tensor      # int64[N+1]
@@ -40,7 +43,7 @@ def make_graph(num_nodes: int, num_directed: int, seed: int, device) -> tuple:
     g.manual_seed(seed)
     N = num_nodes
     perm = torch.randperm(N, generator=g, device=device)
-    n_ranges = max(1, -(-2 * num_directed // (1 << 30)))
+    n_ranges = max(1, -(-2 * num_directed // MAX_KEYS_PER_SORT))
     bounds = torch.tensor([(N * k) // n_ranges for k in range(n_ranges + 1)], device=device, dtype=torch.int64) * N
     pieces = [[] for _ in range(n_ranges)]
     CH = 1 << 25

@@ -99,3 +99,20 @@ def test_csr_permute_symmetric_coalesces_duplicates():
     rp, cl = csr_permute_symmetric(rowptr, col, inv)
     # old edges {(0,1),(0,2),(1,0),(2,0)} -> new {(2,0),(2,1),(0,2),(1,2)}
     assert rp.tolist() == [0, 1, 2, 4] and cl.tolist() == [2, 2, 0, 1]
+
+
+def test_synthetic_graph_is_independent_of_the_sort_range_count(monkeypatch):
+    """papers-scale graphs are coalesced per row range (no sort may see 2^31 keys); the result must be
+    the graph a single global sort gives."""
+    from salient_plusplus_amd import synthetic
+    one = synthetic.make_graph(6000, 50000, 11, torch.device("cpu"))
+    monkeypatch.setattr(synthetic, "MAX_KEYS_PER_SORT", 1 << 13)
+    many = synthetic.make_graph(6000, 50000, 11, torch.device("cpu"))
+    assert torch.equal(one[0], many[0]) and torch.equal(one[1], many[1])
+    rp, col = one
+    assert int(rp[-1]) == col.numel() and bool((rp[1:] >= rp[:-1]).all())
+    # symmetric and coalesced
+    n = rp.numel() - 1
+    row = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    key = row * n + col
+    assert torch.equal(key, torch.unique(key)) and torch.equal(torch.sort(col * n + row).values, key)
