@@ -49,6 +49,18 @@ def _rank_cfg(g, rank, P, offsets, use_cache, nb, bs, fs):
     return cfg, idx
 
 
+def _check_batch(batch, k, ranges, g, idx, x, orc):
+    start, stop = int(ranges[k][0]), int(ranges[k][1])
+    m = orc.sample_batch(g["rowptr"], g["col"], idx, start, stop, SIZES)
+    assert batch.x.is_cuda
+    np.testing.assert_array_equal(batch.x.cpu().numpy().view(np.uint16), x[m.n_id].view(np.uint16))
+    np.testing.assert_array_equal(batch.y.cpu().numpy().reshape(-1), g["y"][m.n_id[:stop - start]])
+    for adj, hop in zip(batch.adjs, m.hops):
+        rp, cl, _ = adj.adj_t.csr()
+        np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
+        np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+
+
 def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stats):
     it = None
     try:
@@ -67,19 +79,16 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
             assert it.session.native_exchange
             pre = DeviceDistributedPrefetcher([dev], it, True)
             got = 0
+            held = []
             for (batch,) in pre:
-                start, stop = int(ranges[got][0]), int(ranges[got][1])
-                m = orc.sample_batch(g["rowptr"], g["col"], idx, start, stop, SIZES)
-                assert batch.x.is_cuda
-                np.testing.assert_array_equal(batch.x.cpu().numpy().view(np.uint16), x[m.n_id].view(np.uint16))
-                np.testing.assert_array_equal(batch.y.cpu().numpy().reshape(-1), g["y"][m.n_id[:stop - start]])
-                for adj, hop in zip(batch.adjs, m.hops):
-                    rp, cl, _ = adj.adj_t.csr()
-                    np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
-                    np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+                held.append(batch)
                 got += 1
                 if got == 2:
                     pre.quiesce()       # every rank at the same batch: all in-flight exchanges complete
+                if epoch == 0:          # epoch 1 compares after the epoch: no host sync between batches
+                    _check_batch(held.pop(), got - 1, ranges, g, idx, x, orc)
+            for k, batch in enumerate(held):
+                _check_batch(batch, k, ranges, g, idx, x, orc)
             assert got == nb
             stats[rank] = pre.NUMBER_OF_SENT_BYTES
             it.session.close()
