@@ -364,15 +364,18 @@ spp_status spp_vip_frequencies(const int64_t* rowptr_dev, const int64_t* col_dev
  * f3  Mean aggregation of SAGEConv over one MFG hop (driver/models.py:19-56: SAGEConv(aggr='mean')
  *     on ((x, x_target), adj_t)); fp32 accumulate and output.
  *       forward : out[t,:] = sum_{e in row t} x[col[e],:] / max(deg t, 1);  x fp32 or fp16, rows
- *                 x_stride_elems apart (the batch's fp16 features can be aggregated directly)
+ *                 x_stride_elems apart (the batch's fp16 features can be aggregated directly);
+ *                 out rows out_stride_elems apart (0 = dense), so the result can land in the left
+ *                 half of the [T, 2F] operand of one fused lin_l|lin_r GEMM
  *       backward: grad_x[col[e],:] += grad_out[t,:] / deg t  (grad_x [S,F] fp32, zeroed by the
  *                 caller; hardware fp32 atomics, so the summation order is not fixed)
  * ------------------------------------------------------------------------- */
 spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                 const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
-                                float* out_dev, void* stream);
+                                float* out_dev, int64_t out_stride_elems, void* stream);
 spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
-                                 const float* grad_out_dev, int64_t F, float* grad_x_dev, void* stream);
+                                 const float* grad_out_dev, int64_t grad_out_stride_elems, int64_t F,
+                                 float* grad_x_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,8 +104,8 @@ SIGNATURES = {
     "spp_comm_rank": (i32, [p]),
     "spp_comm_world": (i32, [p]),
     "spp_vip_frequencies": (C.c_int, [p, p, i64, p, i64, i64, p, i32, p, p, p]),
-    "spp_csr_mean_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, p]),
-    "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, p, p]),
+    "spp_csr_mean_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
+    "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, i64, p, p]),
     "spp_session_quiesce": (C.c_int, [p]),
     "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),
 }

@@ -36,7 +36,7 @@ template <typename Tin, bool VEC4>
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
                                                          const Tin* __restrict__ x, int64_t x_stride, int64_t F,
-                                                         int lpr_log2, float* __restrict__ out) {
+                                                         int lpr_log2, float* __restrict__ out, int64_t out_stride) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
@@ -56,21 +56,22 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
         const f4 v0 = load4(x + col[k] * x_stride + c);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
       }
-      *reinterpret_cast<float4*>(out + t * F + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      *reinterpret_cast<float4*>(out + t * out_stride + c) =
+          make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     }
   } else {
     for (int64_t c = lane; c < F; c += lpr) {
       float acc = 0.f;
       for (int64_t k = b; k < e; ++k) acc += load1(x + col[k] * x_stride + c);
-      out[t * F + c] = acc * inv;
+      out[t * out_stride + c] = acc * inv;
     }
   }
 }
 
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_bwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
-                                                         const float* __restrict__ grad_out, int64_t F, int lpr_log2,
-                                                         float* __restrict__ grad_x) {
+                                                         const float* __restrict__ grad_out, int64_t go_stride,
+                                                         int64_t F, int lpr_log2, float* __restrict__ grad_x) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_bwd(const int64_t* __restri
   if (e <= b) return;
   const float inv = 1.0f / (float)(e - b);
   for (int64_t c = lane; c < F; c += lpr) {
-    const float g = grad_out[t * F + c] * inv;
+    const float g = grad_out[t * go_stride + c] * inv;
     for (int64_t k = b; k < e; ++k) unsafeAtomicAdd(grad_x + col[k] * F + c, g);  // hardware fp32 atomic add
   }
 }
@@ -96,21 +97,23 @@ using namespace spp;
 
 extern "C" spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                            const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
-                                           float* out_dev, void* stream) {
+                                           float* out_dev, int64_t out_stride_elems, void* stream) {
   SPP_REQUIRE(num_targets >= 0 && F >= 0, "spp_csr_mean_forward: negative size");
   if (num_targets == 0 || F == 0) return SPP_OK;
   SPP_REQUIRE(rowptr_dev && out_dev, "spp_csr_mean_forward: NULL buffer");
   SPP_REQUIRE(x_stride_elems >= F, "spp_csr_mean_forward: row stride smaller than the row");
+  if (out_stride_elems <= 0) out_stride_elems = F;
+  SPP_REQUIRE(out_stride_elems >= F, "spp_csr_mean_forward: output stride smaller than the row");
   hipStream_t st = as_stream(stream);
   const int64_t esz = x_is_half ? 2 : 4;
   const bool vec = (F % 4 == 0) && ((x_stride_elems * esz) % (4 * esz) == 0) &&
                    (reinterpret_cast<uintptr_t>(x_dev) % (4 * esz) == 0) &&
-                   (reinterpret_cast<uintptr_t>(out_dev) % 16 == 0);
+                   (reinterpret_cast<uintptr_t>(out_dev) % 16 == 0) && (out_stride_elems % 4 == 0);
   const int lpr_log2 = lanes_log2(vec ? F / 4 : F);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
 #define SPP_AGG(TIN, V)                                                                                          \
   hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, \
-                     static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev)
+                     static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems)
   if (x_is_half) {
     if (vec) SPP_AGG(__half, true); else SPP_AGG(__half, false);
   } else {
@@ -122,14 +125,17 @@ extern "C" spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int6
 }
 
 extern "C" spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
-                                            const float* grad_out_dev, int64_t F, float* grad_x_dev, void* stream) {
+                                            const float* grad_out_dev, int64_t grad_out_stride_elems, int64_t F,
+                                            float* grad_x_dev, void* stream) {
   SPP_REQUIRE(num_targets >= 0 && F >= 0, "spp_csr_mean_backward: negative size");
   if (num_targets == 0 || F == 0) return SPP_OK;
   SPP_REQUIRE(rowptr_dev && grad_out_dev && grad_x_dev, "spp_csr_mean_backward: NULL buffer");
+  if (grad_out_stride_elems <= 0) grad_out_stride_elems = F;
+  SPP_REQUIRE(grad_out_stride_elems >= F, "spp_csr_mean_backward: gradient stride smaller than the row");
   const int lpr_log2 = lanes_log2(F);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
   hipLaunchKernelGGL(k_csr_mean_bwd, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev, num_targets,
-                     grad_out_dev, F, lpr_log2, grad_x_dev);
+                     grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

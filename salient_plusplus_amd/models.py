@@ -18,38 +18,50 @@ def _p(t):
 
 
 class _MeanAggregate(torch.autograd.Function):
-    """out[t] = mean_{e in row t} x[col[e]]  (empty rows give 0, as PyG's mean aggregation)."""
+    """out[t] = mean_{e in row t} x[col[e]]  (empty rows give 0, as PyG's mean aggregation).
+
+    With ``x_target`` the result is the fused operand ``[mean | x_target]`` of shape [T, 2F] (fp32): the
+    aggregation writes its half in place, so lin_l and lin_r become ONE GEMM."""
 
     @staticmethod
-    def forward(ctx, x, rowptr, col, num_targets):
+    def forward(ctx, x, rowptr, col, num_targets, x_target):
         L = nat.load()
         nat.require_device()
         assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.float32)
         Fdim = x.size(1)
-        out = torch.empty((num_targets, Fdim), dtype=torch.float32, device=x.device)
+        width = 2 * Fdim if x_target is not None else Fdim
+        out = torch.empty((num_targets, width), dtype=torch.float32, device=x.device)
         nat.check(L.spp_csr_mean_forward(_p(rowptr), _p(col), num_targets, _p(x), int(x.dtype == torch.float16),
-                                         x.stride(0) if x.size(0) > 1 else Fdim, Fdim, _p(out),
+                                         x.stride(0) if x.size(0) > 1 else Fdim, Fdim, _p(out), width,
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if x_target is not None:
+            out[:, Fdim:].copy_(x_target)
         ctx.save_for_backward(rowptr, col)
-        ctx.shape = (x.size(0), Fdim, num_targets)
+        ctx.shape = (x.size(0), Fdim, num_targets, width)
         ctx.in_dtype = x.dtype
+        ctx.fused = x_target is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None
         rowptr, col = ctx.saved_tensors
-        S, Fdim, T = ctx.shape
-        g = grad_out.contiguous().to(torch.float32)
-        grad_x = torch.zeros((S, Fdim), dtype=torch.float32, device=g.device)
-        nat.check(nat.load().spp_csr_mean_backward(_p(rowptr), _p(col), T, _p(g), Fdim, _p(grad_x),
-                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return grad_x.to(ctx.in_dtype), None, None, None
+        S, Fdim, T, width = ctx.shape
+        grad_x = grad_t = None
+        g = grad_out if (grad_out.stride(1) == 1 and grad_out.dtype == torch.float32) else \
+            grad_out.contiguous().to(torch.float32)
+        if ctx.needs_input_grad[0]:
+            grad_x = torch.zeros((S, Fdim), dtype=torch.float32, device=g.device)
+            nat.check(nat.load().spp_csr_mean_backward(_p(rowptr), _p(col), T, _p(g), g.stride(0) if T > 1 else width,
+                                                       Fdim, _p(grad_x),
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            grad_x = grad_x.to(ctx.in_dtype)
+        if ctx.fused and ctx.needs_input_grad[4]:
+            grad_t = g[:, Fdim:]
+        return grad_x, None, None, None, grad_t
 
 
 def mean_aggregate(x, rowptr, col, num_targets):
-    return _MeanAggregate.apply(x, rowptr, col, num_targets)
+    return _MeanAggregate.apply(x, rowptr, col, num_targets, None)
 
 
 def init_weights(m):                                     # driver/models.py:12-16
@@ -73,8 +85,10 @@ class SAGEConv(torch.nn.Module):
     def forward(self, x_pair, adj_t):
         x, x_target = x_pair
         rowptr, col, _ = adj_t.csr()
-        agg = mean_aggregate(x, rowptr, col, x_target.size(0))
-        return self.lin_l(agg) + self.lin_r(x_target.to(torch.float32))
+        # [mean_j x_j | x_target] @ [W_l | W_r]^T: one GEMM instead of two plus an add
+        fused = _MeanAggregate.apply(x, rowptr, col, x_target.size(0), x_target)
+        out = F.linear(fused, torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1))
+        return out if self.lin_l.bias is None else out + self.lin_l.bias
 
 
 class SAGE(torch.nn.Module):
