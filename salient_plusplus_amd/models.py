@@ -64,6 +64,37 @@ def mean_aggregate(x, rowptr, col, num_targets):
     return _MeanAggregate.apply(x, rowptr, col, num_targets, None)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = a @ w.T for a very tall ``a`` ([T, K], T ~ 1e5) and a small ``w`` ([N, K]).
+
+    The weight gradient ``g.T @ a`` is a [N, K] output reduced over T: as one GEMM it has a handful
+    of output tiles for 256 CUs (measured 505 us at T=165k, K=200, N=256 -- 27 % of the step).  It is
+    computed as a batched GEMM over row slabs (split-K) and summed instead."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return a @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        grad_a = g @ w if ctx.needs_input_grad[0] else None
+        grad_w = None
+        if ctx.needs_input_grad[1]:
+            T = a.size(0)
+            slabs = min(64, T // 4096)
+            if slabs >= 2 and a.is_contiguous() and g.is_contiguous():
+                c = T // slabs
+                head = torch.bmm(g[:slabs * c].view(slabs, c, -1).transpose(1, 2), a[:slabs * c].view(slabs, c, -1))
+                grad_w = head.sum(0)
+                if slabs * c < T:
+                    grad_w = grad_w + g[slabs * c:].t() @ a[slabs * c:]
+            else:
+                grad_w = g.t() @ a
+        return grad_a, grad_w
+
+
 def init_weights(m):                                     # driver/models.py:12-16
     if isinstance(m, torch.nn.Linear):
         torch.nn.init.xavier_uniform_(m.weight, gain=torch.nn.init.calculate_gain("relu"))
@@ -87,7 +118,7 @@ class SAGEConv(torch.nn.Module):
         rowptr, col, _ = adj_t.csr()
         # [mean_j x_j | x_target] @ [W_l | W_r]^T: one GEMM instead of two plus an add
         fused = _MeanAggregate.apply(x, rowptr, col, x_target.size(0), x_target)
-        out = F.linear(fused, torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1))
+        out = _TallLinear.apply(fused, torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1))
         return out if self.lin_l.bias is None else out + self.lin_l.bias
 
 
