@@ -377,6 +377,22 @@ spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int64_t* col_d
                                  const float* grad_out_dev, int64_t grad_out_stride_elems, int64_t F,
                                  float* grad_x_dev, void* stream);
 
+/* GATConv(heads=1) message passing over one MFG hop (driver/models.py:195-231):
+ *   e_ij = leaky_relu(a_src[j] + a_dst[i], negative_slope) over row i without its diagonal entry plus
+ *   the self loop (i, i) that GATConv adds (set_diag);  out[i,:] = sum_j softmax_j(e_ij) h[j,:].
+ *   h fp32 [S,F] dense (targets are its first rows), a_src fp32[S], a_dst fp32[T]; row_max/row_sum
+ *   fp32[T] keep the softmax statistics for the backward pass.  Backward: grad_h [S,F] and
+ *   grad_a_src [S] zeroed by the caller (fp32 atomics), grad_a_dst [T] written. */
+spp_status spp_gat_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                           const float* h_dev, int64_t F, const float* a_src_dev, const float* a_dst_dev,
+                           float negative_slope, float* out_dev, float* row_max_dev, float* row_sum_dev,
+                           void* stream);
+spp_status spp_gat_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                            const float* h_dev, int64_t F, const float* a_src_dev, const float* a_dst_dev,
+                            float negative_slope, const float* out_dev, const float* row_max_dev,
+                            const float* row_sum_dev, const float* grad_out_dev, float* grad_h_dev,
+                            float* grad_a_src_dev, float* grad_a_dst_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

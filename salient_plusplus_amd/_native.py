@@ -106,6 +106,8 @@ SIGNATURES = {
     "spp_vip_frequencies": (C.c_int, [p, p, i64, p, i64, i64, p, i32, p, p, p]),
     "spp_csr_mean_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
     "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, i64, p, p]),
+    "spp_gat_forward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p]),
+    "spp_gat_backward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
     "spp_session_quiesce": (C.c_int, [p]),
     "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),
 }

@@ -149,3 +149,102 @@ class SAGE(torch.nn.Module):
                 x = F.relu(x)
                 x = F.dropout(x, p=0.5, training=self.training)
         return torch.log_softmax(x, dim=-1)
+
+
+# --------------------------------------------------------------------------------------------
+# GAT  (driver/models.py:195-231: GATConv(bias=False, heads=1))
+# --------------------------------------------------------------------------------------------
+class _GatAggregate(torch.autograd.Function):
+    """out[i] = sum_j softmax_j(leaky_relu(a_src[j] + a_dst[i])) h[j] over row i (its diagonal entry
+    dropped) plus the self loop GATConv adds."""
+
+    @staticmethod
+    def forward(ctx, h, a_src, a_dst, rowptr, col, slope):
+        L = nat.load()
+        nat.require_device()
+        h, a_src, a_dst = h.contiguous().float(), a_src.contiguous().float(), a_dst.contiguous().float()
+        T, Fdim = a_dst.numel(), h.size(1)
+        out = torch.empty((T, Fdim), dtype=torch.float32, device=h.device)
+        rmax = torch.empty(T, dtype=torch.float32, device=h.device)
+        rsum = torch.empty(T, dtype=torch.float32, device=h.device)
+        nat.check(L.spp_gat_forward(_p(rowptr), _p(col), T, _p(h), Fdim, _p(a_src), _p(a_dst), float(slope), _p(out),
+                                    _p(rmax), _p(rsum), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ctx.save_for_backward(h, a_src, a_dst, rowptr, col, out, rmax, rsum)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, a_src, a_dst, rowptr, col, out, rmax, rsum = ctx.saved_tensors
+        T, Fdim = a_dst.numel(), h.size(1)
+        g = g.contiguous().float()
+        grad_h = torch.zeros_like(h)
+        grad_as = torch.zeros_like(a_src)
+        grad_ad = torch.zeros_like(a_dst)
+        nat.check(nat.load().spp_gat_backward(_p(rowptr), _p(col), T, _p(h), Fdim, _p(a_src), _p(a_dst), ctx.slope,
+                                              _p(out), _p(rmax), _p(rsum), _p(g), _p(grad_h), _p(grad_as), _p(grad_ad),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return grad_h, grad_as, grad_ad, None, None, None
+
+
+class GATConv(torch.nn.Module):
+    """torch_geometric.nn.GATConv(in, out, heads=1, negative_slope=0.2, dropout=0, add_self_loops=True,
+    bias=...) on a bipartite ((x, x_target), adj_t): one shared linear map for sources and targets
+    (an int ``in_channels``), attention vectors att_src / att_dst, softmax over the incoming edges."""
+
+    def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, bias=True):
+        super().__init__()
+        if heads != 1:
+            raise NotImplementedError("the reference model fixes heads=1 (driver/models.py:197)")
+        self.negative_slope = negative_slope
+        self.lin_src = torch.nn.Linear(in_channels, out_channels, bias=False)
+        self.lin_dst = self.lin_src
+        self.att_src = torch.nn.Parameter(torch.empty(1, 1, out_channels))
+        self.att_dst = torch.nn.Parameter(torch.empty(1, 1, out_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_src.reset_parameters()
+        torch.nn.init.xavier_uniform_(self.att_src)          # PyG: glorot
+        torch.nn.init.xavier_uniform_(self.att_dst)
+        if self.bias is not None:
+            torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x_pair, adj_t):
+        x, x_target = x_pair
+        rowptr, col, _ = adj_t.csr()
+        h = self.lin_src(x.to(torch.float32))                # targets are the first rows of the sources
+        h_t = h[:x_target.size(0)]
+        a_src = (h * self.att_src.view(1, -1)).sum(-1)
+        a_dst = (h_t * self.att_dst.view(1, -1)).sum(-1)
+        out = _GatAggregate.apply(h, a_src, a_dst, rowptr, col, self.negative_slope)
+        return out if self.bias is None else out + self.bias
+
+
+class GAT(torch.nn.Module):
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        self.hidden_channels = hidden_channels
+        self.convs = torch.nn.ModuleList()
+        self.convs.append(GATConv(in_channels, hidden_channels, bias=False, heads=1))
+        for _ in range(num_layers - 2):
+            self.convs.append(GATConv(hidden_channels, hidden_channels, bias=False, heads=1))
+        self.convs.append(GATConv(hidden_channels, out_channels, bias=False, heads=1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+            conv.apply(init_weights)
+
+    def forward(self, x, adjs):
+        x = x.to(torch.float)
+        for i, (adj_t, _e_id, size) in enumerate(adjs):
+            x_target = x[:size[1]]
+            x = self.convs[i]((x, x_target), adj_t)
+            if i != self.num_layers - 1:
+                x = F.relu(x)
+                x = F.dropout(x, p=0.5, training=self.training)
+        return torch.log_softmax(x, dim=-1)

@@ -156,3 +156,64 @@ def test_end_to_end_training_learns_through_the_data_path():
             hit += int((pred == b.y.reshape(-1)).sum())
             tot += pred.numel()
     assert tot == test.numel() and hit / tot > 0.6, hit / tot        # chance is 0.25
+
+
+def _ref_gat(h, a_src, a_dst, rowptr, col, T, slope=0.2):
+    """plain torch: drop diagonal entries, add one self loop per target, edge softmax, weighted sum"""
+    cnt = rowptr[1:] - rowptr[:-1]
+    row = torch.repeat_interleave(torch.arange(T, device=h.device), cnt)
+    keep = col != row
+    row = torch.cat([row[keep], torch.arange(T, device=h.device)])
+    src = torch.cat([col[keep], torch.arange(T, device=h.device)])
+    e = torch.nn.functional.leaky_relu(a_src[src] + a_dst[row], slope)
+    m = torch.full((T,), -float("inf"), device=h.device).scatter_reduce(0, row, e, "amax")
+    w = torch.exp(e - m[row])
+    s = torch.zeros(T, device=h.device).index_add_(0, row, w)
+    return torch.zeros((T, h.size(1)), device=h.device).index_add_(0, row, (w / s[row]).unsqueeze(-1) * h[src])
+
+
+@pytest.mark.parametrize("F", [256, 47, 8, 100])
+def test_gat_aggregate_forward_backward(F):
+    from salient_plusplus_amd.models import _GatAggregate
+    T, S = 2000, 7000
+    rowptr, col = _random_hop(T, S, 15, F)
+    col[::11] = torch.repeat_interleave(torch.arange(T, device="cuda"), rowptr[1:] - rowptr[:-1])[::11]   # some diagonal entries
+    g = torch.Generator().manual_seed(2)
+    h0 = torch.randn((S, F), generator=g).cuda()
+    as0 = torch.randn(S, generator=g).cuda()
+    ad0 = torch.randn(T, generator=g).cuda()
+    ins_a = [t.clone().requires_grad_(True) for t in (h0, as0, ad0)]
+    ins_b = [t.clone().requires_grad_(True) for t in (h0, as0, ad0)]
+    out_a = _GatAggregate.apply(ins_a[0], ins_a[1], ins_a[2], rowptr, col, 0.2)
+    out_b = _ref_gat(ins_b[0], ins_b[1], ins_b[2], rowptr, col, T)
+    torch.testing.assert_close(out_a, out_b, rtol=1e-4, atol=1e-5)
+    w = torch.randn((T, F), device="cuda")
+    (out_a * w).sum().backward()
+    (out_b * w).sum().backward()
+    for a, b in zip(ins_a, ins_b):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_gat_model_runs_and_learns_shapes():
+    from salient_plusplus_amd.fast_trainer.monkeypatch import SparseTensor
+    from salient_plusplus_amd.models import GAT
+    torch.manual_seed(0)
+    T1, T0, S = 50, 300, 1500
+    rp1, c1 = _random_hop(T0, S, 6, 1)
+    rp0, c0 = _random_hop(T1, T0, 6, 2)
+    adjs = [(SparseTensor(rowptr=rp1, col=c1, sparse_sizes=(T0, S)), None, (S, T0)),
+            (SparseTensor(rowptr=rp0, col=c0, sparse_sizes=(T1, T0)), None, (T0, T1))]
+    x = torch.randn((S, 20), device="cuda").half()
+    y = torch.randint(0, 5, (T1,), device="cuda")
+    model = GAT(20, 32, 5, 2).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        out = model(x, adjs)
+        assert out.shape == (T1, 5)
+        loss = torch.nn.functional.nll_loss(out, y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.7 * losses[0]
