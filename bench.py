@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true",
                     help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--prime", type=int, default=16,
+                    help="steps run as part of set-up, before the W warm-up steps: first-touch costs of the "
+                         "allocators, the pooled sampler workspace and the exchange buffers (reported as priming_steps)")
     ap.add_argument("--cache-strategy", default="vip", choices=["vip", "degree", "degree-desc"],
                     help="N>1: ranking of the remote vertices for the feature cache (ddp.py:425-492)")
     ap.add_argument("--split-seeds", action="store_true",
@@ -367,6 +370,9 @@ def main():
                       ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
                        if native else "torch.distributed all_to_all_single per batch")
 
+    # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----
+    for _ in range(max(0, a.prime)):
+        feeder.next()
     # ---- warmup ----
     for _ in range(a.warmup):
         feeder.next()
@@ -441,6 +447,7 @@ def main():
             "config": {"workload": f"{a.workload}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
+            "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
             "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),

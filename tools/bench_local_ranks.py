@@ -18,7 +18,7 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
-wl = make_workload("S-products", device=dev)
+wl = make_workload(os.environ.get("WL", "S-products"), device=dev)
 N, F = wl.num_nodes, wl.x.size(1)
 offsets = torch.linspace(0, N, P + 1).long()
 offsets[-1] = N
@@ -48,9 +48,17 @@ def rank_main(r):
         t0 = time.perf_counter()
         n = 0
         it = iter(sampler)
+        marks = []
         for (b,) in DeviceDistributedPrefetcher([dev], it, True):
             n += 1
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
+        if r == 0 and os.environ.get("SERIES"):
+            ms = torch.cuda.memory_stats()
+            print("allocator: segments allocated", ms["segment.all.allocated"], "freed", ms["segment.all.freed"],
+                  "retries", ms["num_alloc_retries"], "reserved GB", ms["reserved_bytes.all.current"] / 1e9, flush=True)
+            d = [round((marks[i + 1] - marks[i]) * 1e6) for i in range(len(marks) - 1)]
+            print(f"epoch {epoch} per-batch us:", d, flush=True)
         dt = time.perf_counter() - t0
         sent, recv = 0, 0
         res[(r, epoch)] = (n, dt, it.session.total_blocked_dur.total_seconds(), it.session.total_blocked_occasions)
