@@ -1453,7 +1453,7 @@ XBuf* sampler_xbuf(spp_sampler* s, int set) { return &s->xbuf[set % kMaxWorkStre
 
 spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes) {
   if (need <= *cap) return SPP_OK;
-  const int64_t ncap = std::max(need + need / 4, *cap * 2);
+  const int64_t ncap = std::max(need + need / 2, *cap * 2);  // group sizes vary by a few %: do not grow twice
   void* v = nullptr;
   SPP_HIP_TRY(hipMalloc(&v, (size_t)(ncap * unit_bytes)));
   if (*buf) s->allocs.push_back(*buf);  // released by spp_sampler_destroy
