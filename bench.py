@@ -15,6 +15,7 @@ rows fetched over RCCL/xGMI by the native exchange (DeviceDistributedPrefetcher)
 of its own batches (weak scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -373,6 +374,8 @@ def main():
     # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----
     for _ in range(max(0, a.prime)):
         feeder.next()
+    gc.collect()
+    gc.freeze()           # the long-lived set-up objects need not be re-scanned by a collection inside the timed loop
     # ---- warmup ----
     for _ in range(a.warmup):
         feeder.next()
