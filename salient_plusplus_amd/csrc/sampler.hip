@@ -374,12 +374,19 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       chosen[k][tid] = found ? j : option;
     }
   }
-  // all neighbour reads of the row are issued back to back (independent HBM misses)
-  for (int32_t k = 0; k < cnt; ++k) {
-    const int32_t w = smp ? chosen[k][tid] : k;
-    chosen[k][tid] = (int32_t)col[rs + w];
+  // neighbour reads in batches of 8 held in registers: the loads of a batch are all issued before the
+  // first use, so a lane has up to 8 independent HBM misses in flight instead of one per iteration
+  for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
+    int32_t nb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int32_t k = k0 + u;
+      if (k < cnt) nb[u] = (int32_t)col[rs + (smp ? chosen[k][tid] : k)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < cnt) s.cval[p0 + k0 + u] = nb[u];
   }
-  for (int32_t k = 0; k < cnt; ++k) s.cval[p0 + k] = chosen[k][tid];
 }
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
