@@ -72,6 +72,8 @@ struct DedupGeom {
 };
 constexpr int kMaxBucketsLog2 = 12;
 constexpr int kMaxBuckets = 1 << kMaxBucketsLog2;
+constexpr int kMaxFineLog2 = 6;              // a hop's bucket spans at most 2^6 fine buckets
+constexpr int kMaxFinePerCoarse = 1 << kMaxFineLog2;
 constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile kernels (more waves per tile: latency bound)
 constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
                                             // one global atomic reserves room for several edges)
@@ -417,23 +419,24 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
-                                                      DedupGeom g) {
+                                                      int32_t cb_log2) {
   __shared__ int32_t lh[kMaxBuckets];
   __shared__ int32_t lscan[kTileNT / kWave + 1];
   __shared__ int is_last;
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t nbk = 1 << cb_log2;  // buckets of THIS hop (coarser than the known lists for small hops)
   const int32_t E = s.st->error ? 0 : s.st->E[h];
   const int64_t base = (int64_t)blockIdx.x * kBucketTile;
   if (base >= E && blockIdx.x != 0) return;  // tile 0 always takes part (E may be 0)
   const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
-  for (int b = threadIdx.x; b < g.nb; b += kTileNT) lh[b] = 0;
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
   __syncthreads();
   for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
     const int64_t p = base + k;
-    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
+    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], cb_log2)], 1);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < g.nb; b += kTileNT)
+  for (int b = threadIdx.x; b < nbk; b += kTileNT)
     if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
   // last tile: exclusive scan of the bucket counts -> offsets and scatter cursors; counts re-zeroed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own atomics before the barrier
@@ -442,12 +445,12 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
   __syncthreads();
   if (!is_last) return;
   int32_t carry = 0;
-  for (int32_t bb = 0; bb < g.nb; bb += kTileNT) {
+  for (int32_t bb = 0; bb < nbk; bb += kTileNT) {
     const int32_t b = bb + threadIdx.x;
-    const int32_t v = (b < g.nb) ? acquire_i32(&s.bcount[b]) : 0;
+    const int32_t v = (b < nbk) ? acquire_i32(&s.bcount[b]) : 0;
     int32_t tot;
     const int32_t ex = block_exclusive_scan<int32_t, kTileNT>(v, lscan, &tot);
-    if (b < g.nb) {
+    if (b < nbk) {
       s.boff[b] = carry + ex;
       s.bcur[b] = carry + ex;
       s.bcount[b] = 0;
@@ -455,25 +458,26 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
     carry += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) s.boff[g.nb] = carry;
+  if (threadIdx.x == 0) s.boff[nbk] = carry;
 }
 
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                         int32_t h, DedupGeom g) {
+                                                         int32_t h, int32_t cb_log2) {
   __shared__ int32_t lh[kMaxBuckets];    // tile histogram, then running cursor inside the reservation
   __shared__ int32_t lbase[kMaxBuckets]; // start of this tile's reservation in each bucket
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const int32_t nbk = 1 << cb_log2;
   const int32_t E = s.st->E[h];
   const int64_t base = (int64_t)blockIdx.x * kBucketTile;
   if (base >= E || s.st->error) return;
-  for (int b = threadIdx.x; b < g.nb; b += kTileNT) lh[b] = 0;
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
   __syncthreads();
   for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
     const int64_t p = base + k;
-    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], g.nb_log2)], 1);
+    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], cb_log2)], 1);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < g.nb; b += kTileNT) {
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) {
     const int32_t c = lh[b];
     lbase[b] = c ? atomicAdd(&s.bcur[b], c) : 0;
     lh[b] = 0;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     const int64_t p = base + k;
     if (p < E) {
       const uint32_t c = (uint32_t)s.cval[p];
-      const uint32_t b = bucket_of(c, g.nb_log2);
+      const uint32_t b = bucket_of(c, cb_log2);
       const int32_t j = atomicAdd(&lh[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
       s.bpairs[lbase[b] + j] = ((unsigned long long)c << 32) | (uint32_t)p;
     }
@@ -498,38 +502,50 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
 // (node, kPending | p) to the bucket's known list for the later hops.
 template <int LDS_LOG2>
 __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                       int32_t h, DedupGeom g) {
+                                                       int32_t h, DedupGeom g, int32_t cb_log2) {
   __shared__ unsigned long long tab[1 << LDS_LOG2];
-  __shared__ int n_new, ovf;
+  __shared__ int32_t fkc[kMaxFinePerCoarse];   // entries of each fine known list at entry
+  __shared__ int32_t fnew[kMaxFinePerCoarse];  // nodes this hop appends to each
+  __shared__ int ovf;
   constexpr uint32_t mask = (1u << LDS_LOG2) - 1;
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
   if (s.st->error) return;
+  // A hop's bucket is a run of 2^shift consecutive fine buckets (bucket ids are top bits of one hash):
+  // small hops use few, well-filled workgroups instead of thousands that each set up an LDS table
+  // for a handful of edges; the known-node lists stay per FINE bucket for the later, larger hops.
   const int32_t b = blockIdx.x;
+  const int32_t shift = g.nb_log2 - cb_log2;
+  const int32_t nf = 1 << shift;
+  const int32_t fb0 = b << shift;
   const uint32_t T = (uint32_t)s.st->cnt[h];
   const uint32_t Tprev = h > 0 ? (uint32_t)s.st->cnt[h - 1] : 0u;
-  unsigned long long* kl = s.known + (int64_t)b * g.kcap;
-  const int32_t kc = s.kcount[b];
   const int32_t e0 = s.boff[b], e1 = s.boff[b + 1];
   const bool work = e1 > e0;  // block-uniform
-  if (work) {
-    for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
-    if (threadIdx.x == 0) {
-      n_new = 0;
-      ovf = 0;
-    }
-    __syncthreads();
+  for (int i = threadIdx.x; i < nf; i += kNT) {
+    fkc[i] = s.kcount[fb0 + i];
+    fnew[i] = 0;
   }
+  if (work)
+    for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
+  if (threadIdx.x == 0) ovf = 0;
+  __syncthreads();
   // known nodes: resolve the previous hop's pending ids (its rank array is overwritten by this hop's
-  // k_hop_assign, so this must happen now for EVERY bucket), then publish them in the LDS table
-  for (int i = threadIdx.x; i < kc; i += kNT) {
-    unsigned long long e = kl[i];
-    uint32_t val = (uint32_t)e;
-    if (val & kPending) {
-      val = Tprev + (uint32_t)s.erank[val & ~kPending];
-      e = (e & 0xffffffff00000000ull) | val;
-      kl[i] = e;
+  // k_hop_assign, so this must happen now for EVERY list), then publish them in the LDS table;
+  // one wavefront per fine list
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
+    unsigned long long* kl = s.known + (int64_t)(fb0 + lf) * g.kcap;
+    const int32_t kc = fkc[lf];
+    for (int i = lane; i < kc; i += kWave) {
+      unsigned long long e = kl[i];
+      uint32_t val = (uint32_t)e;
+      if (val & kPending) {
+        val = Tprev + (uint32_t)s.erank[val & ~kPending];
+        e = (e & 0xffffffff00000000ull) | val;
+        kl[i] = e;
+      }
+      if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e >> 32), val, &ovf);
     }
-    if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e >> 32), val, &ovf);
   }
   if (!work) return;
   __syncthreads();
@@ -554,16 +570,18 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     const uint32_t key = (uint32_t)(pr >> 32), p = (uint32_t)pr;
     const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
     s.evals[p] = val;
-    if (val == T + p) {  // first occurrence of a new node
-      const int j = atomicAdd(&n_new, 1);
-      if (kc + j < g.kcap) kl[kc + j] = ((unsigned long long)key << 32) | kPending | p;
+    if (val == T + p) {  // first occurrence of a new node: append to its fine list
+      const int32_t lf = (int32_t)bucket_of(key, g.nb_log2) - fb0;
+      const int j = fkc[lf] + atomicAdd(&fnew[lf], 1);
+      if (j < g.kcap) s.known[(int64_t)(fb0 + lf) * g.kcap + j] = ((unsigned long long)key << 32) | kPending | p;
       else ovf = 1;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (ovf) atomicOr(&s.st->error, kErrBucketCap);
-    s.kcount[b] = kc + (n_new < g.kcap - kc ? n_new : g.kcap - kc);
+  if (threadIdx.x == 0 && ovf) atomicOr(&s.st->error, kErrBucketCap);
+  for (int i = threadIdx.x; i < nf; i += kNT) {
+    const int32_t room = g.kcap - fkc[i];
+    s.kcount[fb0 + i] = fkc[i] + (fnew[i] < room ? fnew[i] : room);
   }
 }
 
@@ -904,6 +922,7 @@ struct spp_sampler {
   bool generic[SPP_MAX_HOPS];
   bool any_generic = false;
   DedupGeom geom{};
+  int cb_log2[SPP_MAX_HOPS];        // bucket bits of hop h (<= geom.nb_log2; fewer for small hops)
   int lds_log2 = 12;                // LDS table slots of k_bucket_dedup (12: 32 KB, 13: 64 KB, 14: 128 KB)
   int64_t bytes = 0;
   std::vector<SlotHost> slots;
@@ -998,6 +1017,12 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   const int64_t per_bucket = (ucap + s->geom.nb - 1) / s->geom.nb;
   s->geom.kcap = (int32_t)std::min<int64_t>(per_bucket + per_bucket / 2 + 256, 0x7fffffff);
   s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 2048 ? 13 : 12);
+  for (int h = 0; h < H; ++h) {
+    // as few buckets as keep the hop's worst-case node count per bucket within the LDS table's budget
+    int c = std::max(0, nb_log2 - kMaxFineLog2);
+    while (c < nb_log2 && (s->tcap[h + 1] >> c) > 1536) ++c;
+    s->cb_log2[h] = c;
+  }
   const int nb = s->geom.nb;
   int64_t tmax = 0;
   for (int h = 0; h < H; ++h) tmax = std::max(tmax, s->tcap[h]);
@@ -1271,17 +1296,16 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
-    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, geom);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, geom);
+    const int32_t cb = s->cb_log2[h];
+    const unsigned nbk = 1u << cb;
+    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
     if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
-                         geom);
+      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
     else if (s->lds_log2 == 13)
-      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
-                         geom);
+      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
     else
-      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((unsigned)geom.nb, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h,
-                         geom);
+      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
     hipLaunchKernelGGL(k_hop_flag, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
     hipLaunchKernelGGL(k_hop_scan2, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f,
                        (int32_t)s->tcap[H]);
