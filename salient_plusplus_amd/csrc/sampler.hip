@@ -44,6 +44,11 @@
 #include <cstdlib>
 #include <vector>
 
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+
 #include "gather_body.cuh"
 #include "partition_common.cuh"
 
@@ -197,6 +202,15 @@ __global__ __launch_bounds__(kMtThreads) void k_rng_fill(const SlotPtrs* __restr
   mt_block_advance(x, 624, skip + dcap, skip, cap, out);
 }
 
+// One-off int32 copy of the neighbour array (node ids are < 2^31, fast_sampler.cpp:196-199 narrows them
+// anyway): a sampled row spans half as many 128-B fetch granules, and the random neighbour reads of the
+// last hop are the sampler's largest single source of HBM traffic.
+__global__ __launch_bounds__(256) void k_narrow_col(const int64_t* __restrict__ col, int64_t nnz,
+                                                    int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256)
+    out[i] = (int32_t)col[i];
+}
+
 // get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
 // seed keeps its LAST position: every seed is appended to its bucket's known list and the LDS
 // insert of known entries takes the max.
@@ -317,9 +331,9 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
 // ----------------------------------------------------------------------------------------------
-template <bool kGeneric>
+template <bool kGeneric, typename ColT>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                   int32_t rng_buf, const int64_t* __restrict__ col, int32_t h,
+                                                   int32_t rng_buf, const ColT* __restrict__ col, int32_t h,
                                                    int32_t f, int32_t replace) {
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, then neighbour ids; column per lane
@@ -392,8 +406,9 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
 }
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
+template <typename ColT>
 __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                             const int64_t* __restrict__ col, int32_t h, int32_t f,
+                                                             const ColT* __restrict__ col, int32_t h, int32_t f,
                                                              int32_t replace) {
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
   const int32_t T = s.st->cnt[h];
@@ -901,6 +916,20 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
 // ================================================================================================
 using namespace spp;
 
+// int32 copy of a neighbour array, shared by every sampler created over the same (pointer, nnz, device)
+struct Col32 {
+  int32_t* p = nullptr;
+  int device = 0;
+  ~Col32() {
+    if (p) {
+      (void)hipSetDevice(device);
+      (void)hipFree(p);
+    }
+  }
+};
+static std::mutex g_col32_mu;
+static std::map<std::tuple<const void*, int64_t, int>, std::weak_ptr<Col32>> g_col32;
+
 struct SlotHost {
   SlotPtrs p{};
   hipEvent_t done = nullptr;        // own event object
@@ -936,6 +965,8 @@ struct spp_sampler {
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
   int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
+  std::shared_ptr<Col32> col32_owner;  // int32 copy of cfg.col_dev, shared by the samplers of one graph
+  int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
   XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
 };
@@ -1116,6 +1147,35 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       rc = SPP_ERR_HIP;
     }
   }
+  if (rc == SPP_OK && cfg->nnz > 0) {
+    const char* e = getenv("SPP_COL32");
+    if (!e || atoi(e) != 0) {
+      std::lock_guard<std::mutex> lk(g_col32_mu);
+      const auto key = std::make_tuple((const void*)cfg->col_dev, cfg->nnz, (int)cfg->device);
+      std::shared_ptr<Col32> c = g_col32[key].lock();
+      if (!c) {
+        c = std::make_shared<Col32>();
+        c->device = cfg->device;
+        if (hipMalloc((void**)&c->p, sizeof(int32_t) * (size_t)cfg->nnz) != hipSuccess) {
+          c->p = nullptr;
+          set_error("spp_sampler_create: hipMalloc of the int32 neighbour array failed");
+          rc = SPP_ERR_HIP;
+        } else {
+          hipLaunchKernelGGL(k_narrow_col, dim3(256 * 16), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, c->p);
+          if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            set_error("spp_sampler_create: narrowing the neighbour array failed");
+            rc = SPP_ERR_HIP;
+          }
+        }
+        if (rc == SPP_OK) g_col32[key] = c;
+      }
+      if (rc == SPP_OK) {
+        s->col32_owner = c;
+        s->col32 = c->p;
+        s->bytes += (int64_t)sizeof(int32_t) * cfg->nnz;
+      }
+    }
+  }
   if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) rc = SPP_ERR_HIP;
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
   if (rc == SPP_ERR_HIP) set_error("spp_sampler_create: stream creation failed");
@@ -1246,6 +1306,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const int H = s->cfg.num_hops;
   const int64_t* rowptr = s->cfg.rowptr_dev;
   const int64_t* col = s->cfg.col_dev;
+  const int32_t* col32 = s->col32;
   const int32_t replace = s->cfg.replace ? 1 : 0;
   GroupArgs ga{};
   ga.first_slot = first_slot;
@@ -1278,8 +1339,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     hipLaunchKernelGGL(k_hop_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f, ecap_dev, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_pick<false>, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col, h, f,
-                         replace);
+      if (col32)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf,
+                           col32, h, f, replace);
+      else
+        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf,
+                           col, h, f, replace);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -1289,10 +1354,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       if (lead.host_state->error) break;
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL(k_hop_pick<true>, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col, h, f,
-                         replace);
-      hipLaunchKernelGGL(k_hop_expand_generic, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h, f,
-                         replace);
+      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col,
+                         h, f, replace);
+      if (col32)
+        hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col32,
+                           h, f, replace);
+      else
+        hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col,
+                           h, f, replace);
     }
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
