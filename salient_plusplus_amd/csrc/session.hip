@@ -417,10 +417,29 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   const size_t cnt_elems = (size_t)s->G * (size_t)s->P;
   for (size_t k = 0; k < s->xsets.size(); ++k) s->xsets[k].b = sampler_xbuf(s->sampler, (int)k);
   for (auto& x : s->xsets) {
-    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_elems * 8 * (size_t)(s->P + 2)));
-    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_elems * 8 * (size_t)(s->P + 2), hipHostMallocDefault));
+    const size_t cnt_bytes = 8 * (cnt_elems * (size_t)(s->P + 2) + 2 * (size_t)s->P + 2);  // + the creation-time check
+    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_bytes));
+    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_bytes, hipHostMallocDefault));
     SPP_HIP_TRY(hipEventCreateWithFlags(&x.cnt_ready, hipEventDisableTiming));
     SPP_HIP_TRY(hipEventCreateWithFlags(&x.rows_done, hipEventDisableTiming));
+  }
+  // Collective sanity check: the exchange is one collective sequence per group, so every rank must
+  // run the same number of batches in groups of the same size (force_exact_num_batches in the
+  // reference's distributed mode); a mismatch would otherwise show up as a hang.
+  {
+    XSet& x0 = s->xsets[0];
+    x0.cnt_host[0] = (int64_t)s->ranges.size();
+    x0.cnt_host[1] = s->G;
+    SPP_HIP_TRY(hipMemcpyAsync(x0.cnt_dev, x0.cnt_host, 16, hipMemcpyHostToDevice, s->comm_stream));
+    SPP_TRY(tr->all_gather(x0.cnt_dev, x0.cnt_dev + 2, 16, s->comm_stream));
+    SPP_HIP_TRY(hipMemcpyAsync(x0.cnt_host + 2, x0.cnt_dev + 2, 16 * (size_t)s->P, hipMemcpyDeviceToHost, s->comm_stream));
+    SPP_HIP_TRY(hipStreamSynchronize(s->comm_stream));
+    for (int m = 0; m < s->P; ++m)
+      SPP_REQUIRE(x0.cnt_host[2 + 2 * m] == x0.cnt_host[0] && x0.cnt_host[3 + 2 * m] == x0.cnt_host[1],
+                  "spp_session_create: rank %d runs %lld batches in groups of %lld, rank %d runs %lld in groups of %lld "
+                  "(every rank must run the same number of batches)",
+                  s->rank, (long long)x0.cnt_host[0], (long long)x0.cnt_host[1], m, (long long)x0.cnt_host[2 + 2 * m],
+                  (long long)x0.cnt_host[3 + 2 * m]);
   }
   s->tr = tr;
   return SPP_OK;

@@ -317,3 +317,37 @@ def test_partitioned_dataset_from_disk_through_exchange(tmp_path):
         c.close()
     assert not errors, "\n".join(errors)
     assert not any(t.is_alive() for t in ts)
+
+
+def test_mismatched_batch_counts_are_refused_not_hung():
+    """Ranks that would run different numbers of batches are told so at Session creation (the exchange
+    is one collective sequence per group; the mismatch would otherwise be a hang)."""
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    comms = fs.NativeComm.local(2)
+    out = {}
+
+    def run(r):
+        try:
+            torch.cuda.set_device(0)
+            fs.set_native_comm(comms[r])
+            cfg, _ = _rank_cfg(g, r, 2, [0, 1400, n], False, 3 + r, 16, fs)      # 3 batches on rank 0, 4 on rank 1
+            iter(FastSampler(2, 4, cfg))
+            out[r] = "created"
+        except nat.SppError as e:
+            out[r] = str(e)
+        finally:
+            fs.set_native_comm(None)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    for c in comms:
+        c.close()
+    assert not any(t.is_alive() for t in ts)
+    assert all("same number of batches" in out[r] for r in range(2)), out
