@@ -152,8 +152,17 @@ class EpochFeeder:
         self.make_iter, self.shuffler, self.get_idx = make_iter, shuffler, get_idx
         self.epoch = 0
         self.devit = None
+        self._xb = (0, 0)
+
+    def exchange_bytes(self):
+        """(sent, received) bytes of the native exchange over all epochs so far (0, 0 without one)."""
+        sess = getattr(getattr(self.devit, "it", None), "session", None)
+        cur = sess.exchange_bytes() if sess is not None and getattr(sess, "native_exchange", False) else (0, 0)
+        return self._xb[0] + cur[0], self._xb[1] + cur[1]
 
     def _new_epoch(self):
+        if self.devit is not None:
+            self._xb = self.exchange_bytes()
         self.shuffler.set_epoch(self.epoch)
         self.devit = self.make_iter(self.get_idx())
         self.epoch += 1
@@ -386,6 +395,7 @@ def main():
     torch.cuda.synchronize()
     L.spp_profile_enable(1)
     edges = nodes = 0
+    xb0 = feeder.exchange_bytes()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         b = feeder.next()
@@ -397,6 +407,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    xb1 = feeder.exchange_bytes()
     # gather-kernel time, measured live with HIP events on the launching stream
     ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
     # SPP_PROF_GATHER: the fused delivery launch (also assembles x with the native exchange);
@@ -457,6 +468,14 @@ def main():
             "graph_build_s": t_build,
             "roofline": roof,
         }
+        if distributed and native:
+            # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
+            # by up to the slot-sets in flight, so this is within one group of the bytes of the K batches)
+            sent, recv = xb1[0] - xb0[0], xb1[1] - xb0[1]
+            out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI", "rank0_sent_MB_per_batch": sent / a.steps / 1e6,
+                               "rank0_received_MB_per_batch": recv / a.steps / 1e6,
+                               "rank0_GBps_out": sent / dt / 1e9, "rank0_GBps_in": recv / dt / 1e9,
+                               "xgmi_peak_GBps_per_gpu": 7 * 153.0}
         if not a.no_model_step and not distributed:
             try:
                 m_only, m_data = model_step_timing(feeder, F, 47, hip=True)
