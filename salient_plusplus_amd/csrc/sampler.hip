@@ -1176,9 +1176,11 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       }
     }
   }
-  if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) rc = SPP_ERR_HIP;
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
-  if (rc == SPP_ERR_HIP) set_error("spp_sampler_create: stream creation failed");
+  if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("spp_sampler_create: stream creation failed");
+    rc = SPP_ERR_HIP;
+  }
   if (rc == SPP_OK) {
     std::vector<SlotPtrs> tmp((size_t)nslots);
     for (int i = 0; i < nslots; ++i) tmp[(size_t)i] = s->slots[(size_t)i].p;

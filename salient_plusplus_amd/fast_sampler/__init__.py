@@ -316,6 +316,7 @@ class NativeComm:
         return [NativeComm(C.c_void_p(arr[m]), m, world) for m in range(world)]
 
 
+_trimmed_for_exchange = False
 _comm_tls = threading.local()
 _comm_auto = {}
 _comm_lock = threading.Lock()
@@ -391,7 +392,13 @@ class _SamplerPool:
         if part is not None:
             cfg.part = part[0]
         h = C.c_void_p()
-        nat.check(L.spp_sampler_create(C.byref(cfg), C.byref(h)))
+        rc = L.spp_sampler_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            # the workspace is allocated with hipMalloc: give back what torch's caching allocator
+            # hoards (e.g. temporaries of a dataset build) and try once more
+            torch.cuda.empty_cache()
+            rc = L.spp_sampler_create(C.byref(cfg), C.byref(h))
+        nat.check(rc)
         return (h, max_batch, slots, (rowptr_d, col_d, part[2] if part is not None else None), key)
 
     @classmethod
@@ -513,6 +520,12 @@ class Session:
                 self._xc = xc
                 cfg.exchange = C.pointer(xc)
                 self.native_exchange = True
+                global _trimmed_for_exchange
+                if not _trimmed_for_exchange:
+                    # the exchange buffers are hipMalloc'ed by the library as the first groups size them:
+                    # hand back what torch's caching allocator hoards from set-up, once per process
+                    torch.cuda.empty_cache()
+                    _trimmed_for_exchange = True
         h = C.c_void_p()
         try:
             nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))

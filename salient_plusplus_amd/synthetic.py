@@ -98,4 +98,6 @@ def make_workload(name: str, seed: int = 1234, device=None) -> Workload:
         x[i:j] = torch.randn((j - i, F), generator=g, device=device, dtype=torch.float32).to(torch.float16)
     y = torch.randint(0, 47, (N,), generator=g, device=device, dtype=torch.int64)
     train_idx = torch.randperm(N, generator=g, device=device)[:n_train].contiguous()
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()      # the sort temporaries of a papers-scale build are tens of GB
     return Workload(name, rowptr, col, x, y, train_idx, list(fanouts), bs)
