@@ -242,8 +242,17 @@ def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
             "batches_per_s": nb / dt}
 
 
+def _trace(msg):
+    """progress markers on stderr (SPP_BENCH_TRACE=1): where a multi-rank run stops making progress"""
+    if os.environ.get("SPP_BENCH_TRACE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
+    if os.environ.get("SPP_BENCH_TRACE") == "1":
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("SPP_BENCH_TRACE_AFTER", "60")), exit=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,8 +298,18 @@ def main():
 
     L = nat.load()
     nat.require_device()
+    _trace("process group up, building the workload")
     t_build = time.perf_counter()
-    wl = make_workload(a.workload, seed=1234, device=dev)
+    if distributed and os.environ.get("SPP_BENCH_REHEARSAL") == "1":
+        # several processes on ONE GPU: torch.unique (single-pass look-back scan) was seen to hang when
+        # four processes ran it concurrently on the same device -- build one rank at a time
+        for r in range(world):
+            if r == rank:
+                wl = make_workload(a.workload, seed=1234, device=dev)
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        wl = make_workload(a.workload, seed=1234, device=dev)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     N, F = wl.num_nodes, wl.x.size(1)
@@ -320,6 +339,7 @@ def main():
         lo, hi = int(offsets[rank]), int(offsets[rank + 1])
         x_local = wl.x[lo:hi].contiguous()
         pb = fs.RangePartitionBook(rank, world, offsets)
+        _trace("workload built, building the feature cache")
         # VIP cache (ddp.py:417-570): the remote vertices most likely to be touched by this rank's
         # mini-batches (analytic model, ddp.py:135-239, on the GPU), alpha * N / P rows fetched from
         # their owners once.  --cache-strategy degree-desc keeps the earlier top-degree proxy.
@@ -336,6 +356,7 @@ def main():
             n_cache = int(cache.cached_vertices.numel())
         else:
             cache = fs.Cache()
+        _trace(f"cache built ({n_cache} rows)")
         # Seeds.  Weak scaling keeps the per-GPU work fixed: every rank runs the N=1 epoch (n_train // bs
         # batches) on its own seeded permutation of the training ids, so epoch boundaries (a pipeline
         # refill each) are as frequent as at N=1.  --split-seeds gives the reference's split instead
@@ -381,17 +402,22 @@ def main():
                        if native else "torch.distributed all_to_all_single per batch")
 
     # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----
-    for _ in range(max(0, a.prime)):
+    _trace("iterator ready, priming")
+    for k in range(max(0, a.prime)):
         feeder.next()
+        _trace(f"primed batch {k}")
     gc.collect()
     gc.freeze()           # the long-lived set-up objects need not be re-scanned by a collection inside the timed loop
     # ---- warmup ----
     for _ in range(a.warmup):
         feeder.next()
     torch.cuda.synchronize()
+    _trace("warm-up done")
     if distributed:
         feeder.quiesce()      # nothing of the exchange's communicator in flight while the barrier's kernels run
+        _trace("quiesced")
         dist.barrier()
+        _trace("barrier passed, timing")
     torch.cuda.synchronize()
     L.spp_profile_enable(1)
     edges = nodes = 0
