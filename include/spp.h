@@ -284,6 +284,9 @@ spp_status spp_session_batch_ranges(const spp_session* s, int32_t* out_start_sto
 /* BLOCKING. Returns 1 and fills *out when the next batch (index order) is ready,
  * 0 at end of epoch (the reference returns None), <0 on error. */
 int spp_session_next(spp_session* s, spp_batch_desc* out);
+/* Non-blocking form (try_get_batch, fast_sampler.cpp:658-670): 2 when the next batch is not ready
+ * yet, otherwise exactly what spp_session_next returns. */
+int spp_session_try_next(spp_session* s, spp_batch_desc* out);
 /* Write the batch returned by the last spp_session_next into caller buffers on
  * `stream`: MFG (as spp_sampler_export), optional x = x_src[n_id] and
  * y = y_src[n_id[:stop-start]]; then recycle its slot (the next pending batch

@@ -108,6 +108,7 @@ SIGNATURES = {
     "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, i64, p, p]),
     "spp_gat_forward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p]),
     "spp_gat_backward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
+    "spp_session_try_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
     "spp_session_quiesce": (C.c_int, [p]),
     "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),
 }

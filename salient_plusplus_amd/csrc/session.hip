@@ -640,6 +640,27 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   return 1;
 }
 
+extern "C" int spp_session_try_next(spp_session* s, spp_batch_desc* out) {
+  if (!s || !out) {
+    set_error("spp_session_try_next: NULL argument");
+    return SPP_ERR_INVALID;
+  }
+  if (s->current_slot < 0 && s->next_to_deliver < (int64_t)s->ranges.size()) {
+    // is the next batch ready?  (chain launched and complete; with the native exchange: issued)
+    const int64_t g = s->next_to_deliver / s->G;
+    const int32_t slot = (int32_t)((g % s->num_sets) * s->G + s->next_to_deliver % s->G);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (s->launch_rc == SPP_OK && s->exchange_rc == SPP_OK &&
+          (s->chain_launched <= g || (s->tr && s->exchange_launched <= g)))
+        return 2;
+    }
+    hipEvent_t ev = sampler_slot_event(s->sampler, slot);
+    if (ev && hipEventQuery(ev) == hipErrorNotReady) return 2;
+  }
+  return spp_session_next(s, out);  // ready (or an error to report / a batch to drop): does not block now
+}
+
 extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg, const void* x_src_dev, int64_t x_rows,
                                          int64_t x_row_bytes, int64_t x_src_stride_bytes, void* x_out_dev,
                                          const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,

@@ -620,10 +620,11 @@ class Session:
         return int(self._L.spp_session_blocked_occasions(self._h))
 
     # ---- batch production ----
-    def _next_desc(self):
-        rc = self._L.spp_session_next(self._h, C.byref(self._desc))
+    def _next_desc(self, block=True):
+        fn = self._L.spp_session_next if block else self._L.spp_session_try_next
+        rc = fn(self._h, C.byref(self._desc))
         nat.check(rc)
-        return rc == 1
+        return rc == 1          # 0: end of data, 2: not ready yet (non-blocking form only)
 
     def _alloc_mfg(self, counts, want_n_id=True, num_parts=0):
         """One int64 arena per batch for n_id and every hop's rowptr/col (a single allocator call
@@ -678,10 +679,10 @@ class Session:
             return out, n_id, adjs, buckets
         return out, n_id, adjs
 
-    def blocking_get_batch(self):
+    def blocking_get_batch(self, _block=True):
         """-> None or (x, y-or-None, [(rowptr, col, e_id, (T, S)) ...], (start, stop))
         (worker non-distributed branch, fast_sampler.cpp:1004-1016)."""
-        if not self._next_desc():
+        if not self._next_desc(_block):
             return None
         d = self._desc
         c = d.counts
@@ -696,7 +697,9 @@ class Session:
         self._export(out, x, y)
         return (x, y, adjs, (int(d.start), int(d.stop)))
 
-    try_get_batch = blocking_get_batch
+    def try_get_batch(self):
+        """Non-blocking (fast_sampler.cpp:658-670): None when no batch is ready yet or none is left."""
+        return self.blocking_get_batch(_block=False)
 
     def _export(self, out, x, y):
         xa = self._x_args if x is not None and self._x is not None else (None, 0, 0, 0)
@@ -707,9 +710,9 @@ class Session:
             ya[0], ya[1], ya[2], C.c_void_p(y.data_ptr()) if ya[0] is not None and y.numel() else None,
             C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)))
 
-    def blocking_get_batch_distributed(self):
+    def blocking_get_batch_distributed(self, _block=True):
         """-> None or ProtoDistributedBatch (worker distributed branch, fast_sampler.cpp:1017-1272)."""
-        if not self._next_desc():
+        if not self._next_desc(_block):
             return None
         d = self._desc
         c = d.counts
@@ -742,7 +745,9 @@ class Session:
             self._count_remote(b.partition_nids, rank)
         return b
 
-    try_get_batch_distributed = blocking_get_batch_distributed
+    def try_get_batch_distributed(self):
+        """Non-blocking (fast_sampler.cpp:672-711): None when the next batch (index order) is not ready."""
+        return self.blocking_get_batch_distributed(_block=False)
 
     def _native_distributed_batch(self, d, c, P, rank, use_cache):
         """The exchange already ran natively (session.hip): one launch delivers the MFG, the labels

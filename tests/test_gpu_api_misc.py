@@ -39,11 +39,15 @@ def test_session_properties_and_errors(fs, graph_a):
     assert s.num_total_batches == 4 and s.num_consumed_batches == 0
     assert isinstance(s.total_blocked_dur, datetime.timedelta) and s.total_blocked_occasions >= 0
     assert s.config.batch_size == 64
-    n = 0
-    while s.try_get_batch() is not None:
+    n = polls = 0
+    while s.num_consumed_batches < s.num_total_batches:    # the reference's polling pattern (:783-799)
+        polls += 1
+        if s.try_get_batch() is None:                      # not ready yet: never blocks
+            continue
         n += 1
         assert s.num_consumed_batches == n == s.approx_num_complete_batches
-    assert n == 4 and s.blocking_get_batch() is None       # end of data stays None
+    assert n == 4 and polls >= 4
+    assert s.try_get_batch() is None and s.blocking_get_batch() is None       # end of data stays None
     s.close()
     bad = base_cfg(fs, graph_a, force_exact_num_batches=True, exact_num_batches=1000)
     with pytest.raises(RuntimeError):
