@@ -1,16 +1,18 @@
-"""Python façade over the MI355X ``fast_sampler`` module -- same public names and field sets as the
-reference's fast_trainer/samplers.py (``FastSamplerConfig`` :271-305, ``FastSampler`` :372-399,
-``FastSamplerIter`` :331-357, ``PreparedBatch`` :213-268, ``ProtoDistributedBatch`` :32-165,
-``Adj__from_fast_sampler`` :22-30), so ``fast_trainer.train`` / the drivers run unchanged.
+"""Batch records, sampler configuration and sampler iterables of the training façade.
 
-All tensors of a batch are already in HBM when the iterator yields them; ``.to(device)`` and
-``.pin_memory()`` on them are therefore no-ops and ``record_stream`` is what keeps them safe
-across streams.
+This module offers the names the rest of SALIENT++ imports from ``fast_trainer.samplers`` -- the batch
+records (``PreparedBatch``, ``ProtoBatch``, ``ProtoDistributedBatch``), ``Adj__from_fast_sampler``,
+``FastSamplerConfig``, ``FastSampler`` / ``FastSamplerIter`` / ``FastPreSampler`` and the two statistics
+records -- with the field sets and call signatures of the reference (fast_trainer/samplers.py:22-30,
+:32-165, :213-268, :271-305, :331-423), on top of the MI355X ``fast_sampler`` module.
+
+Every tensor of a batch already lives in HBM when an iterator yields it: moving a batch ``.to`` its
+own device returns the same storage and ``record_stream`` is what makes hand-over between streams safe.
 """
+import dataclasses
 import datetime
 import itertools
 from abc import abstractmethod
-from dataclasses import dataclass, fields
 from typing import Iterable, Iterator, List, NamedTuple, Optional, Sized
 
 import torch
@@ -20,64 +22,138 @@ from ..fast_sampler import Cache, RangePartitionBook
 from .monkeypatch import Adj, SparseTensor
 
 
+# --------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------
+def _mark_in_use(stream, *tensors):
+    """record_stream on every CUDA tensor given (None and host tensors are skipped)"""
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(stream)
+
+
+def _moved(t, device, non_blocking):
+    return None if t is None else t.to(device=device, non_blocking=non_blocking)
+
+
 def Adj__from_fast_sampler(adj) -> Adj:
-    """(rowptr, col, e_id, (T, S)) -> Adj(SparseTensor[T x S] CSR, e_id, size=(S, T))  (samplers.py:22-30)."""
-    rowptr, col, e_id, sparse_sizes = adj
-    adj_t = SparseTensor(rowptr=rowptr, row=None, col=col, value=None, sparse_sizes=sparse_sizes,
-                         is_sorted=True, trust_data=True)
-    return Adj(adj_t, e_id, sparse_sizes[::-1])
+    """One hop as the native module returns it, ``(rowptr, col, e_id, (T, S))``, becomes the PyG-style
+    ``Adj``: a CSR ``SparseTensor`` of T target rows over S source columns, the (empty) edge ids and
+    ``size = (S, T)``."""
+    row_pointers, columns, edge_ids, (n_targets, n_sources) = adj
+    matrix = SparseTensor(rowptr=row_pointers, row=None, col=columns, value=None,
+                          sparse_sizes=(n_targets, n_sources), is_sorted=True, trust_data=True)
+    return Adj(matrix, edge_ids, (n_sources, n_targets))
+
+
+def _hops(raw_adjs) -> List[Adj]:
+    return [Adj__from_fast_sampler(h) for h in raw_adjs]
+
+
+def _as_slice(bounds) -> slice:
+    first, last = bounds
+    return slice(first, last)
+
+
+# --------------------------------------------------------------------------------------------
+# batch records
+# --------------------------------------------------------------------------------------------
+class PreparedBatch(NamedTuple):
+    """A batch ready for the model: features of all MFG nodes (targets first), labels of the seeds,
+    the hops outermost first and the seed range it covers."""
+    x: torch.Tensor
+    y: Optional[torch.Tensor]
+    adjs: List[Adj]
+    idx_range: slice
+
+    # -- constructors --
+    @classmethod
+    def from_fast_sampler(cls, prepared_sample):
+        feats, labels, raw_adjs, bounds = prepared_sample
+        return cls(feats, None if labels is None else labels.squeeze(), _hops(raw_adjs), _as_slice(bounds))
+
+    @classmethod
+    def from_proto_batch(cls, x, y, proto_batch: "ProtoBatch"):
+        nodes = proto_batch.n_id
+        labels = None if y is None else y[nodes[:proto_batch.batch_size]]
+        return cls(x[nodes], labels, proto_batch.adjs, proto_batch.idx_range)
+
+    # -- movement / stream safety --
+    def to(self, device, non_blocking=False):
+        return PreparedBatch(_moved(self.x, device, non_blocking), _moved(self.y, device, non_blocking),
+                             [hop.to(device=device, non_blocking=non_blocking) for hop in self.adjs],
+                             self.idx_range)
+
+    def record_stream(self, stream):
+        _mark_in_use(stream, self.x, self.y)
+        for hop in self.adjs:
+            hop.record_stream(stream)
+
+    # -- sizes --
+    @property
+    def batch_size(self):
+        return self.idx_range.stop - self.idx_range.start
+
+    @property
+    def num_total_nodes(self):
+        return self.x.size(0)
+
+
+class ProtoBatch(NamedTuple):
+    """A sampled batch without features: MFG node ids, hops, seed range."""
+    n_id: torch.Tensor
+    adjs: List[Adj]
+    idx_range: slice
+
+    @classmethod
+    def from_fast_sampler(cls, proto_sample):
+        nodes, raw_adjs, bounds = proto_sample
+        return cls(nodes, _hops(raw_adjs), _as_slice(bounds))
+
+    @property
+    def batch_size(self):
+        return self.idx_range.stop - self.idx_range.start
 
 
 class ProtoDistributedBatch(NamedTuple):
-    """Sampled, not yet feature-complete batch of one rank (samplers.py:32-165):
-    ``cat([feat(partition_nids[0]), ..., feat(partition_nids[P-1]), cache[cached_nids]])[perm]``
-    is the feature matrix in MFG order."""
+    """One rank's sampled batch before the feature exchange.  With ``feat(ids)`` the rows of the
+    owner of ``ids``, the features in MFG order are
+    ``cat([feat(partition_nids[0]), ..., feat(partition_nids[P-1]), cache[cached_nids]])[perm_partition_to_mfg]``;
+    ``cached_nids`` index the cache's own rows.  The GPU session adds the MFG node ids, and -- when the
+    exchange ran natively -- ``x``, the finished feature matrix."""
     partition_nids: List[torch.Tensor]
     sliced_cpu_features: torch.Tensor
     sliced_cpu_labels: torch.Tensor
-    cached_nids: torch.Tensor          # indices INTO cache.cached_features
+    cached_nids: torch.Tensor
     perm_partition_to_mfg: torch.Tensor
     adjs: List[Adj]
     idx_range: slice
-    n_id: Optional[torch.Tensor] = None    # MFG node ids (extra of the GPU path)
-    x: Optional[torch.Tensor] = None       # native exchange: features already assembled in MFG order
-    partition_nids_flat: Optional[torch.Tensor] = None   # cat(partition_nids) when they share one buffer
+    n_id: Optional[torch.Tensor] = None
+    x: Optional[torch.Tensor] = None
+    partition_nids_flat: Optional[torch.Tensor] = None      # all partition_nids as one buffer, when they share one
 
     @classmethod
     def from_fast_sampler(cls, batch):
-        assert batch.sliced_cpu_features is not None
-        start, stop = batch.idx_range
-        return cls(partition_nids=batch.partition_nids,
-                   sliced_cpu_features=batch.sliced_cpu_features,
-                   sliced_cpu_labels=batch.sliced_cpu_labels,
-                   cached_nids=batch.cached_nids,
-                   perm_partition_to_mfg=batch.perm_partition_to_mfg,
-                   adjs=[Adj__from_fast_sampler(a) for a in batch.adjs],
-                   idx_range=slice(start, stop),
-                   n_id=getattr(batch, "n_id", None),
-                   x=getattr(batch, "x", None),
-                   partition_nids_flat=getattr(batch, "partition_nids_flat", None))
-
-    def record_stream(self, stream):
-        for part in self.partition_nids:
-            if part.is_cuda:
-                part.record_stream(stream)
-        for t in (self.perm_partition_to_mfg, self.cached_nids, self.n_id, self.x):
-            if t is not None and t.is_cuda:
-                t.record_stream(stream)
-        for adj in self.adjs:
-            adj.record_stream(stream)
+        if batch.sliced_cpu_features is None:
+            raise AssertionError("the native batch carries no sliced_cpu_features")
+        extras = {name: getattr(batch, name, None) for name in ("n_id", "x", "partition_nids_flat")}
+        return cls(batch.partition_nids, batch.sliced_cpu_features, batch.sliced_cpu_labels, batch.cached_nids,
+                   batch.perm_partition_to_mfg, _hops(batch.adjs), _as_slice(batch.idx_range), **extras)
 
     def to(self, device, stream=None, non_blocking=False, streams_to_sync=None, delay_feature_transfer=True):
         with torch.cuda.stream(stream):
-            adjs = [adj.to(device, non_blocking=non_blocking) for adj in self.adjs]
-            parts = [p.to(device, non_blocking=non_blocking) for p in self.partition_nids]
-            perm = self.perm_partition_to_mfg.to(device, non_blocking=non_blocking)
-            feats = self.sliced_cpu_features
+            changed = dict(
+                adjs=[hop.to(device, non_blocking=non_blocking) for hop in self.adjs],
+                partition_nids=[ids.to(device, non_blocking=non_blocking) for ids in self.partition_nids],
+                perm_partition_to_mfg=self.perm_partition_to_mfg.to(device, non_blocking=non_blocking))
             if not delay_feature_transfer:
-                feats = feats.to(device, non_blocking=non_blocking)
-        return self._replace(adjs=adjs, partition_nids=parts, perm_partition_to_mfg=perm,
-                             sliced_cpu_features=feats)
+                changed["sliced_cpu_features"] = self.sliced_cpu_features.to(device, non_blocking=non_blocking)
+        return self._replace(**changed)
+
+    def record_stream(self, stream):
+        _mark_in_use(stream, *self.partition_nids, self.perm_partition_to_mfg, self.cached_nids, self.n_id, self.x)
+        for hop in self.adjs:
+            hop.record_stream(stream)
 
     @property
     def num_total_nodes(self):
@@ -91,69 +167,15 @@ class ProtoDistributedBatch(NamedTuple):
         return self.partition_nids[local_rank].numel()
 
     def get_num_communicated_nodes(self, local_rank):
-        return sum(p.numel() for i, p in enumerate(self.partition_nids) if i != local_rank)
+        return sum(ids.numel() for owner, ids in enumerate(self.partition_nids) if owner != local_rank)
 
 
-class ProtoBatch(NamedTuple):
-    n_id: torch.Tensor
-    adjs: List[Adj]
-    idx_range: slice
-
-    @classmethod
-    def from_fast_sampler(cls, proto_sample):
-        n_id, adjs, (start, stop) = proto_sample
-        return cls(n_id=n_id, adjs=[Adj__from_fast_sampler(a) for a in adjs], idx_range=slice(start, stop))
-
-    @property
-    def batch_size(self):
-        return self.idx_range.stop - self.idx_range.start
-
-
-class PreparedBatch(NamedTuple):
-    """(x [U,F] in MFG order, y, adjs outermost hop first, idx_range)  (samplers.py:213-268)."""
-    x: torch.Tensor
-    y: Optional[torch.Tensor]
-    adjs: List[Adj]
-    idx_range: slice
-
-    @classmethod
-    def from_proto_batch(cls, x, y, proto_batch: ProtoBatch):
-        return cls(x=x[proto_batch.n_id],
-                   y=y[proto_batch.n_id[:proto_batch.batch_size]] if y is not None else None,
-                   adjs=proto_batch.adjs, idx_range=proto_batch.idx_range)
-
-    @classmethod
-    def from_fast_sampler(cls, prepared_sample):
-        x, y, adjs, (start, stop) = prepared_sample
-        return cls(x=x, y=y.squeeze() if y is not None else None,
-                   adjs=[Adj__from_fast_sampler(a) for a in adjs], idx_range=slice(start, stop))
-
-    def record_stream(self, stream):
-        if self.x is not None and self.x.is_cuda:
-            self.x.record_stream(stream)
-        if self.y is not None and self.y.is_cuda:
-            self.y.record_stream(stream)
-        for adj in self.adjs:
-            adj.record_stream(stream)
-
-    def to(self, device, non_blocking=False):
-        return PreparedBatch(
-            x=self.x.to(device=device, non_blocking=non_blocking) if self.x is not None else None,
-            y=self.y.to(device=device, non_blocking=non_blocking) if self.y is not None else None,
-            adjs=[adj.to(device=device, non_blocking=non_blocking) for adj in self.adjs],
-            idx_range=self.idx_range)
-
-    @property
-    def num_total_nodes(self):
-        return self.x.size(0)
-
-    @property
-    def batch_size(self):
-        return self.idx_range.stop - self.idx_range.start
-
-
-@dataclass
+# --------------------------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------------------------
+@dataclasses.dataclass
 class FastSamplerConfig:
+    """Everything a Session needs; the field names are those of the native ``Config``."""
     x_cpu: torch.Tensor
     x_gpu: torch.Tensor
     y: torch.Tensor
@@ -173,30 +195,32 @@ class FastSamplerConfig:
     use_cache: bool
 
     def to_fast_sampler(self) -> fast_sampler.Config:
-        c = fast_sampler.Config()
-        for field in fields(self):
-            if not self.distributed and field.name == 'partition_book':
+        native = fast_sampler.Config()
+        for f in dataclasses.fields(self):
+            # a single-GPU configuration has no partition book to hand over
+            if f.name == "partition_book" and not self.distributed:
                 continue
-            setattr(c, field.name, getattr(self, field.name))
-        return c
+            setattr(native, f.name, getattr(self, f.name))
+        return native
 
     def get_num_batches(self) -> int:
+        """Number of batches a Session over this configuration will deliver."""
         if self.force_exact_num_batches:
             return self.exact_num_batches
-        num_batches, r = divmod(self.idx.numel(), self.batch_size)
-        if not self.skip_nonfull_batch and r > 0:
-            num_batches += 1
-        return num_batches
+        full, rest = divmod(self.idx.numel(), self.batch_size)
+        return full + (1 if rest and not self.skip_nonfull_batch else 0)
 
 
+# --------------------------------------------------------------------------------------------
+# statistics records
+# --------------------------------------------------------------------------------------------
 class FastSamplerStats(NamedTuple):
     total_blocked_dur: datetime.timedelta
     total_blocked_occasions: int
 
     @classmethod
     def from_session(cls, session):
-        return cls(total_blocked_dur=session.total_blocked_dur,
-                   total_blocked_occasions=session.total_blocked_occasions)
+        return cls(session.total_blocked_dur, session.total_blocked_occasions)
 
 
 class FastSamplerDistributedStats(NamedTuple):
@@ -205,30 +229,31 @@ class FastSamplerDistributedStats(NamedTuple):
 
     @classmethod
     def from_session(cls, session):
-        assert session.num_consumed_batches == session.num_total_batches
+        if session.num_consumed_batches != session.num_total_batches:
+            raise AssertionError("remote-frequency statistics are read after the epoch has been consumed")
         session.reduce_multithreaded_frequency_counts()
-        return cls(remote_frequency_tensor=session.remote_frequency_tensor,
-                   remote_vertices_ordered_by_freq=session.remote_vertices_ordered_by_freq)
+        return cls(session.remote_frequency_tensor, session.remote_vertices_ordered_by_freq)
 
 
+# --------------------------------------------------------------------------------------------
+# iterables
+# --------------------------------------------------------------------------------------------
 class FastSamplerIter(Iterator[PreparedBatch]):
+    """One epoch: owns the native Session (``.session``) and yields its batches in index order."""
     session: fast_sampler.Session
 
     def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig):
-        ncfg = cfg.to_fast_sampler()
-        self.session = fast_sampler.Session(num_threads, max_items_in_queue, ncfg)
-        assert self.session.num_total_batches == cfg.get_num_batches()
+        self.session = fast_sampler.Session(num_threads, max_items_in_queue, cfg.to_fast_sampler())
+        expected = cfg.get_num_batches()
+        if self.session.num_total_batches != expected:
+            raise AssertionError(f"session plans {self.session.num_total_batches} batches, the configuration {expected}")
 
     def __next__(self):
-        if not self.session.config.distributed:
-            sample = self.session.blocking_get_batch()
-            if sample is None:
-                raise StopIteration
-            return PreparedBatch.from_fast_sampler(sample)
-        sample = self.session.blocking_get_batch_distributed()
-        if sample is None:
+        distributed = self.session.config.distributed
+        raw = self.session.blocking_get_batch_distributed() if distributed else self.session.blocking_get_batch()
+        if raw is None:
             raise StopIteration
-        return ProtoDistributedBatch.from_fast_sampler(sample)
+        return (ProtoDistributedBatch if distributed else PreparedBatch).from_fast_sampler(raw)
 
     def get_stats(self) -> FastSamplerStats:
         return FastSamplerStats.from_session(self.session)
@@ -238,6 +263,8 @@ class FastSamplerIter(Iterator[PreparedBatch]):
 
 
 class ABCNeighborSampler(Iterable[PreparedBatch], Sized):
+    """A sampler whose seed set can be replaced between epochs."""
+
     @property
     @abstractmethod
     def idx(self) -> torch.Tensor:
@@ -249,12 +276,19 @@ class ABCNeighborSampler(Iterable[PreparedBatch], Sized):
         ...
 
 
-@dataclass
+@dataclasses.dataclass
 class FastSampler(ABCNeighborSampler):
     num_threads: int
     max_items_in_queue: int
     cfg: FastSamplerConfig
 
+    def __iter__(self):
+        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg)
+
+    def __len__(self):
+        return self.cfg.get_num_batches()
+
+    # the epoch's seeds and the feature cache live in the configuration
     @property
     def idx(self):
         return self.cfg.idx
@@ -271,18 +305,21 @@ class FastSampler(ABCNeighborSampler):
     def cache(self, cache: Cache) -> None:
         self.cfg.cache = cache
 
-    def __iter__(self):
-        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg)
+
+@dataclasses.dataclass
+class FastPreSampler(ABCNeighborSampler):
+    """Samples the whole epoch up front with ``full_sample`` and replays it.  (The reference reads a
+    non-existent ``cfg.x`` here, samplers.py:402-423; the features come from ``cfg.x_cpu``.)"""
+    cfg: FastSamplerConfig
+
+    def __iter__(self) -> Iterator[PreparedBatch]:
+        c = self.cfg
+        per_thread = fast_sampler.full_sample(c.x_cpu, c.y, c.rowptr, c.col, c.idx, c.batch_size, c.sizes,
+                                              c.skip_nonfull_batch, c.pin_memory)
+        return map(PreparedBatch.from_fast_sampler, itertools.chain.from_iterable(per_thread))
 
     def __len__(self):
         return self.cfg.get_num_batches()
-
-
-@dataclass
-class FastPreSampler(ABCNeighborSampler):
-    """Samples the whole epoch up front (samplers.py:402-423; the reference reads a non-existent
-    ``cfg.x`` there -- here the features come from ``cfg.x_cpu``)."""
-    cfg: FastSamplerConfig
 
     @property
     def idx(self):
@@ -291,12 +328,3 @@ class FastPreSampler(ABCNeighborSampler):
     @idx.setter
     def idx(self, idx: torch.Tensor) -> None:
         self.cfg.idx = idx
-
-    def __iter__(self) -> Iterator[PreparedBatch]:
-        cfg = self.cfg
-        p = fast_sampler.full_sample(cfg.x_cpu, cfg.y, cfg.rowptr, cfg.col, cfg.idx, cfg.batch_size,
-                                     cfg.sizes, cfg.skip_nonfull_batch, cfg.pin_memory)
-        return (PreparedBatch.from_fast_sampler(s) for s in itertools.chain(*p))
-
-    def __len__(self):
-        return self.cfg.get_num_batches()

@@ -1,40 +1,53 @@
-"""Per-epoch seeded shuffling of the training ids -- defines the seed order the sampler sees
-(reference: fast_trainer/shufflers.py:6-45: seed = 2147483647 + epoch, randperm on the ids' device,
-per-rank contiguous slice)."""
+"""Seed order of an epoch.  The sampler sees the training ids in the order these classes produce, so
+they follow the reference's rule exactly (fast_trainer/shufflers.py:6-45): a CPU generator seeded with
+``2147483647 + epoch`` permutes the ids; in distributed runs each rank takes one contiguous slice of
+the common permutation, or -- "federated" -- permutes only the ids of its own partition."""
 import torch
 
 
 class Shuffler:
+    """Permutes ``idx`` afresh for every epoch, reproducibly."""
+
     DEFAULT_INITIAL_SEED = 2147483647
 
     def __init__(self, idx: torch.Tensor, initial_seed: int = DEFAULT_INITIAL_SEED):
-        assert idx.dim() == 1
+        if idx.dim() != 1:
+            raise AssertionError("the training ids must form a vector")
         self.initial_idx = idx
         self.initial_seed = initial_seed
-        self.generator = torch.Generator(device='cpu')
         self.epoch = 0
+        # The permutation always comes from the CPU generator (where the reference keeps its ids), so
+        # a given (seed, epoch) orders the ids identically whether they live on the host or in HBM.
+        self.generator = torch.Generator(device="cpu")
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
-    def get_idx(self):
+    def _permutation(self) -> torch.Tensor:
         self.generator.manual_seed(self.initial_seed + self.epoch)
-        # the permutation is always drawn by the CPU generator (what the reference does for its
-        # host-resident ids), so a given (seed, epoch) orders the ids identically wherever they live
-        perm = torch.randperm(self.initial_idx.numel(), generator=self.generator)
-        return self.initial_idx[perm.to(self.initial_idx.device)]
+        return torch.randperm(self.initial_idx.numel(), generator=self.generator)
+
+    def get_idx(self):
+        order = self._permutation().to(self.initial_idx.device)
+        return self.initial_idx[order]
 
 
 class DistributedShuffler(Shuffler):
+    """All ranks draw the same permutation; rank r trains on its r-th contiguous share of it."""
+
     def __init__(self, idx, world_size, initial_seed=Shuffler.DEFAULT_INITIAL_SEED):
         super().__init__(idx, initial_seed)
         self.world_size = world_size
 
     def get_idx(self, rank):
-        shuffled = super().get_idx()
-        n = shuffled.numel()
-        return shuffled[(n * rank) // self.world_size:(n * (rank + 1)) // self.world_size]
+        everything = super().get_idx()
+        total = everything.numel()
+        first = (total * rank) // self.world_size
+        last = (total * (rank + 1)) // self.world_size
+        return everything[first:last]
 
 
 class FederatedDistributedShuffler(Shuffler):
-    """Each rank shuffles the training ids of its own partition (shufflers.py:92-101)."""
+    """Each rank permutes the training ids of its OWN partition (pass only those): batches are not
+    globally random, and unequal partitions give unequal batch sizes once the number of iterations is
+    forced to be the same on every rank.  Behaves exactly like ``Shuffler``."""

@@ -1,5 +1,5 @@
-"""Batchwise evaluation loop (reference: fast_trainer/test.py:8-33): the inference-time consumer of
-the data path (fanout [20,20,20] in the reference's launcher)."""
+"""Evaluation over a ``DeviceIterator`` -- the inference-time consumer of the data path
+(``batchwise_test`` of the reference's fast_trainer/test.py; the launcher uses fanout [20,20,20])."""
 import torch
 
 from .concepts import TestCallback
@@ -8,21 +8,21 @@ from .transferers import DeviceIterator
 
 @torch.no_grad()
 def batchwise_test(model: torch.nn.Module, num_batches: int, devit: DeviceIterator, cb: TestCallback = None):
-    """-> (number of correct predictions, number of evaluated seeds)."""
+    """Counts correct top-1 predictions over every batch of ``devit`` (single device).
+
+    Returns ``(correct, evaluated)``.  The per-batch counts stay on the device until the end, so the
+    loop never waits for the GPU."""
     model.eval()
-    device, = devit.devices
-    on_gpu = torch.device(device).type == "cuda"
-    results = torch.empty(num_batches, dtype=torch.long, pin_memory=on_gpu)
-    total = 0
-    for i, inputs in enumerate(devit):
-        inp, = inputs
-        out = model(inp.x, inp.adjs)
-        out = out.argmax(dim=-1, keepdim=True).reshape(-1)
-        correct = (out == inp.y.reshape(-1)).sum()
-        results[i].copy_(correct, non_blocking=True)
-        total += inp.batch_size
+    if len(devit.devices) != 1:
+        raise ValueError("batchwise_test evaluates on exactly one device")
+    device = torch.device(devit.devices[0])
+    hits = torch.zeros(max(1, num_batches), dtype=torch.long, device=device)
+    evaluated = seen = 0
+    for (batch,) in devit:
+        predicted = model(batch.x, batch.adjs).argmax(dim=-1).reshape(-1)
+        hits[seen % hits.numel()] += (predicted == batch.y.reshape(-1)).sum()
+        evaluated += batch.batch_size
+        seen += 1
         if cb is not None:
-            cb(inp)
-    if on_gpu:
-        torch.cuda.current_stream(device).synchronize()
-    return results.sum().item(), total
+            cb(batch)
+    return int(hits.sum().item()), evaluated
