@@ -176,15 +176,14 @@ class RangePartitionBook:
 
     def nid2partid(self, nids: torch.Tensor) -> torch.Tensor:
         # searchsorted(partition_offsets, nids, right=True) - 1   (range_partition_book.cpp:98-100)
-        if nids.is_cuda:
-            offs = self._offsets_host()
-            src = nids.contiguous().to(torch.int64)
-            out = torch.empty_like(src)
-            nat.check(_lib().spp_nid2partid(C.c_void_p(offs.data_ptr()), offs.numel(), _ptr(src), src.numel(),
-                                            _ptr(out), _stream_ptr()))
-            return out
-        # host tensors are handled by the same ATen op the reference calls
-        return torch.searchsorted(self.partition_offsets.to(nids.device), nids, right=True) - 1
+        # one implementation: host tensors are looked up on the GPU too and come back as host tensors
+        offs = self._offsets_host()
+        L = _lib()
+        src = nids.to(_device(), torch.int64).contiguous()
+        out = torch.empty_like(src)
+        nat.check(L.spp_nid2partid(C.c_void_p(offs.data_ptr()), offs.numel(), _ptr(src), src.numel(),
+                                   _ptr(out), _stream_ptr()))
+        return out if nids.is_cuda else out.to(nids.device)
 
     def nid_is_local(self, nids: torch.Tensor) -> torch.Tensor:
         lo = self.partition_offsets[self.rank].to(nids.device)
