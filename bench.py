@@ -2,7 +2,10 @@
 """Hot-path benchmark: sampled-edges/s of the mini-batch data pipeline (neighbour sampling ->
 MFG -> feature/label slice -> PreparedBatch in HBM) on the dataset BASELINE.json's metric is quoted
 on: ogbn-papers100M scale (synthetic, seeded: 111 M nodes, 3.2 G symmetric nnz, F=128 fp16 -- 56 GB
-of topology + features, which fit one MI355X), GraphSAGE fanout [15,10,5], batch 1024.
+of topology + features, which fit one MI355X), GraphSAGE fanout [15,10,5], batch 1024.  The graph
+carries a planted 8-block locality (80 % intra-block edges) as the stand-in for the METIS partitions
+BASELINE.json's multi-GPU configurations name (synthetic.py: LOCALITY; `--workload S-papers-uniform`
+is the same graph without it -- identical single-GPU numbers, 7/8 of all neighbours remote on 8 GPUs).
 `--workload S-products` runs BASELINE.json's configs[1] instead.
 
   python bench.py --gpus N --steps K --warmup W
@@ -11,8 +14,9 @@ of topology + features, which fit one MI355X), GraphSAGE fanout [15,10,5], batch
 A "step" is one batch through the hot path.  N == 1: single-GPU iterator (FastSampler +
 DevicePrefetcher), all features in HBM.  N > 1: one process per GPU, replicated topology, features
 range-partitioned N ways with a VIP cache of remote rows (analytic model, 10 % of N/P), cache-miss
-rows fetched over RCCL/xGMI by the native exchange (DeviceDistributedPrefetcher); every rank runs K
-of its own batches (weak scaling).  Rank 0 prints ONE JSON line.
+rows fetched over RCCL/xGMI by the native exchange (DeviceDistributedPrefetcher); every rank samples
+from the training vertices of its own partition (the reference launcher's "federated" default) and
+runs K batches (weak scaling).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import gc
@@ -51,9 +55,9 @@ def parse():
                          "allocators, the pooled sampler workspace and the exchange buffers (reported as priming_steps)")
     ap.add_argument("--cache-strategy", default="vip", choices=["vip", "degree", "degree-desc"],
                     help="N>1: ranking of the remote vertices for the feature cache (ddp.py:425-492)")
-    ap.add_argument("--split-seeds", action="store_true",
-                    help="N>1: give each rank 1/N of the training ids per epoch (the reference's DistributedShuffler) "
-                         "instead of a full-length permutation of its own")
+    ap.add_argument("--seed-scheme", default="federated", choices=["federated", "global"],
+                    help="N>1: each rank trains on the training vertices of its own partition (the reference "
+                         "launcher's default) or on a 1/N slice of one global permutation")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -292,7 +296,7 @@ def main():
     from salient_plusplus_amd import _native as nat
     from salient_plusplus_amd import fast_sampler as fs
     from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
-    from salient_plusplus_amd.fast_trainer.shufflers import DistributedShuffler, Shuffler
+    from salient_plusplus_amd.fast_trainer.shufflers import DistributedShuffler, FederatedDistributedShuffler, Shuffler
     from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher, DevicePrefetcher
     from salient_plusplus_amd.synthetic import make_workload
 
@@ -344,6 +348,10 @@ def main():
         # mini-batches (analytic model, ddp.py:135-239, on the GPU), alpha * N / P rows fetched from
         # their owners once.  --cache-strategy degree-desc keeps the earlier top-degree proxy.
         from salient_plusplus_amd.fast_trainer.vip_cache import create_vip_cache, fetch_cache_rows
+        # the vertices this rank's mini-batches start from (ddp.py:33-34 feeds the VIP model with
+        # split_idx_parts[rank]['train'])
+        vip_seeds = wl.train_idx[(wl.train_idx >= lo) & (wl.train_idx < hi)].contiguous() \
+            if a.seed_scheme == "federated" else wl.train_idx
         n_cache = int(a.cache_frac * N / world) if world > 1 else 0
         if n_cache > 0 and a.cache_strategy == "degree-desc":
             deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
@@ -352,25 +360,29 @@ def main():
             cache = fs.Cache(rank, world, cv, cf)
         elif n_cache > 0:
             cache = create_vip_cache(pb, N, x_local, a.cache_frac * 100.0, a.cache_strategy, rowptr=wl.rowptr,
-                                     col=wl.col, train_idx=wl.train_idx, fanouts=sizes, batch_size=bs)
+                                     col=wl.col, train_idx=vip_seeds, fanouts=sizes, batch_size=bs)
             n_cache = int(cache.cached_vertices.numel())
         else:
             cache = fs.Cache()
         _trace(f"cache built ({n_cache} rows)")
-        # Seeds.  Weak scaling keeps the per-GPU work fixed: every rank runs the N=1 epoch (n_train // bs
-        # batches) on its own seeded permutation of the training ids, so epoch boundaries (a pipeline
-        # refill each) are as frequent as at N=1.  --split-seeds gives the reference's split instead
-        # (shufflers.py:32-45: one global permutation, contiguous 1/N slice per rank, epochs N times
-        # shorter).  Either way every rank runs the same number of batches of `bs` seeds
-        # (force_exact_num_batches keeps the exchanges aligned).
-        if a.split_seeds:
+        # Seeds.  "federated" (default; the reference launcher's default, utils/exp_driver.py:113 and
+        # shufflers.py:92-101): every rank shuffles the training vertices of ITS partition, which is what
+        # lets a locality-preserving partition keep most sampled neighbours local.  "global": one seeded
+        # permutation of all training ids, contiguous 1/N slice per rank (shufflers.py:32-45).  Every
+        # rank runs the same number of batches of `bs` seeds (force_exact_num_batches keeps the
+        # exchanges aligned): the smallest pool decides.
+        if a.seed_scheme == "federated":
+            mine = wl.train_idx[(wl.train_idx >= lo) & (wl.train_idx < hi)].contiguous()
+            shuffler = FederatedDistributedShuffler(mine)
+            get_idx = shuffler.get_idx
+            pool = torch.tensor([mine.numel()], device=dev)
+            if world > 1:
+                dist.all_reduce(pool, op=dist.ReduceOp.MIN)
+            n_local = int(pool.item())
+        else:
             shuffler = DistributedShuffler(wl.train_idx, world)
             get_idx = lambda: shuffler.get_idx(rank)                       # noqa: E731
             n_local = wl.train_idx.numel() // world
-        else:
-            shuffler = Shuffler(wl.train_idx, Shuffler.DEFAULT_INITIAL_SEED + 7919 * rank)
-            get_idx = shuffler.get_idx
-            n_local = wl.train_idx.numel()
         cfg = FastSamplerConfig(
             x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=x_local, y=y2, rowptr=wl.rowptr, col=wl.col,
             idx=get_idx(), batch_size=bs, sizes=sizes, skip_nonfull_batch=False, pin_memory=False,
@@ -397,7 +409,7 @@ def main():
             os.environ["SPP_DIST_TRANSPORT"] = "torch"
             native = False
         parallelism = f"dp{world}: features range-partitioned {world}-way, {a.cache_strategy} cache " \
-                      f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {max(1, n_local // bs)} batches per rank and epoch, " + \
+                      f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {a.seed_scheme} seeds, {max(1, n_local // bs)} batches per rank and epoch, " + \
                       ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
                        if native else "torch.distributed all_to_all_single per batch")
 
@@ -450,6 +462,10 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt, edges, nodes = float(tmax[0]), float(tot[0]), float(tot[1])
 
+    from salient_plusplus_amd.synthetic import LOCALITY
+    locality_note = ""
+    if a.workload in LOCALITY:
+        locality_note = f" (planted {LOCALITY[a.workload][0]}-block locality, {LOCALITY[a.workload][1]:.0%} intra-block edges)"
     if rank == 0:
         # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
         row_bytes = F * 2
@@ -484,7 +500,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64/fp16-copy",
             "data": "synthetic",
-            "config": {"workload": f"{a.workload}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
+            "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
             "priming_steps": max(0, a.prime),

@@ -13,7 +13,18 @@ WORKLOADS = {
     "S-products": (2_449_029, 61_859_140, 100, 196_615, [15, 10, 5], 1024),
     # ogbn-papers100M scale: 111 M nodes, ~3.2 G symmetric nnz (col 25.8 GB int64), F=128 fp16 (28.4 GB)
     "S-papers": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
+    "S-papers-uniform": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
 }
+
+# Planted partition locality.  The multi-GPU configurations of BASELINE.json are METIS partitions of
+# real graphs (few cut edges, vertices relabelled so that a partition is a contiguous id range,
+# driver/dataset.py:299-353).  A uniformly random graph has no such partition to find -- 7/8 of all
+# neighbours would be remote on 8 GPUs whatever the partitioner -- so the papers-scale stand-in plants
+# one: the id space is cut into LOCALITY_BLOCKS contiguous blocks and an edge's second endpoint is
+# drawn from the first endpoint's block with probability q (80 % intra-block edges = a 20 % edge cut
+# at 8 parts, less at 4 and 2 since the contiguous range partitions are unions of blocks).
+# "S-papers-uniform" is the same graph without it.  name -> (blocks, q)
+LOCALITY = {"S-papers": (8, 0.8)}
 
 
 MAX_KEYS_PER_SORT = 1 << 30     # torch.unique / CUB take fewer than 2^31 keys per call
@@ -34,8 +45,9 @@ class Workload(NamedTuple):
         return self.rowptr.numel() - 1
 
 
-def make_graph(num_nodes: int, num_directed: int, seed: int, device) -> tuple:
+def make_graph(num_nodes: int, num_directed: int, seed: int, device, locality=None) -> tuple:
     """endpoints src = perm[floor(N*u^2)], dst = floor(N*v): a few very high degree hubs, long tail.
+    `locality` = (blocks, q): with probability q, dst is drawn from src's block of N/blocks ids instead.
 
     The (row, col) keys are sorted and coalesced per ROW RANGE so that no single sort sees 2^31 keys
     (papers100M scale has 3.2 G of them); with one range this is exactly one global unique()."""
@@ -54,6 +66,14 @@ def make_graph(num_nodes: int, num_directed: int, seed: int, device) -> tuple:
         v = torch.rand(m, generator=g, device=device, dtype=torch.float64)
         src = perm[(u * u * N).long().clamp_(max=N - 1)]
         dst = (v * N).long().clamp_(max=N - 1)
+        if locality is not None:
+            blocks, q = locality
+            w = torch.rand(m, generator=g, device=device, dtype=torch.float64)
+            blk = (src * blocks) // N                                    # block of the first endpoint
+            lo = (blk * N + blocks - 1) // blocks                        # first id of that block
+            hi = ((blk + 1) * N + blocks - 1) // blocks
+            inside = lo + (v * (hi - lo).double()).long().clamp_(min=0)
+            dst = torch.where(w < q, torch.minimum(inside, hi - 1), dst)
         keep = src != dst
         src, dst = src[keep], dst[keep]
         if n_ranges == 1:
@@ -88,7 +108,7 @@ def make_workload(name: str, seed: int = 1234, device=None) -> Workload:
     N, m, F, n_train, fanouts, bs = WORKLOADS[name]
     if device is None:
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    rowptr, col = make_graph(N, m, seed, device)
+    rowptr, col = make_graph(N, m, seed, device, LOCALITY.get(name))
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1)
     x = torch.empty((N, F), device=device, dtype=torch.float16)
