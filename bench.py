@@ -167,6 +167,9 @@ class EpochFeeder:
     def _new_epoch(self):
         if self.devit is not None:
             self._xb = self.exchange_bytes()
+            # finish the old epoch's Session first: its sampler (workspace, exchange buffers) goes back to
+            # the pool and the new Session reuses it instead of building a second one
+            self.devit = None
         self.shuffler.set_epoch(self.epoch)
         self.devit = self.make_iter(self.get_idx())
         self.epoch += 1
