@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true",
                     help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N>1: skip the bit-exact check of one group of batches through the native exchange")
     ap.add_argument("--prime", type=int, default=16,
                     help="steps run as part of set-up, before the W warm-up steps: first-touch costs of the "
                          "allocators, the pooled sampler workspace and the exchange buffers (reported as priming_steps)")
@@ -368,6 +370,20 @@ def main():
         else:
             cache = fs.Cache()
         _trace(f"cache built ({n_cache} rows)")
+        # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
+        # all of them fall back to the torch.distributed transport together
+        try:
+            native = fs.native_comm() is not None
+            native_err = None
+        except Exception as e:  # noqa: BLE001
+            native, native_err = False, repr(e)
+        flag = torch.tensor([1 if native else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            if native_err and rank == 0:
+                print(f"[bench] native exchange unavailable: {native_err}", file=sys.stderr, flush=True)
+            os.environ["SPP_DIST_TRANSPORT"] = "torch"
+            native = False
         # Seeds.  "federated" (default; the reference launcher's default, utils/exp_driver.py:113 and
         # shufflers.py:92-101): every rank shuffles the training vertices of ITS partition, which is what
         # lets a locality-preserving partition keep most sampled neighbours local.  "global": one seeded
@@ -393,24 +409,30 @@ def main():
             exact_num_batches=max(1, n_local // bs), count_remote_frequency=False, use_cache=n_cache > 0)
         sampler = FastSampler(4, a.slots, cfg)
 
+        # Parity on the real transport, outside the timed region: every rank holds the whole synthetic
+        # feature matrix, so one group of batches through the native exchange can be compared bit for
+        # bit with x_full[n_id] (what a single GPU would deliver).  Collective: all ranks run it.
+        exchange_verified = None
+        if native and not a.no_verify:
+            import dataclasses
+            n_check = min(8, max(1, n_local // bs))
+            vcfg = dataclasses.replace(cfg, idx=get_idx()[:n_check * bs].contiguous(), exact_num_batches=n_check)
+            vit = iter(FastSampler(4, a.slots, vcfg))
+            good = vit.session.native_exchange
+            for proto in vit:
+                good = good and proto.x is not None and bool(torch.equal(proto.x, wl.x[proto.n_id]))
+            vit.session.quiesce()
+            vit.session.close()
+            del vit
+            flag = torch.tensor([1 if good else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            exchange_verified = bool(int(flag.item()))
+            _trace(f"exchange verified: {exchange_verified}")
+
         def make_iter(idx):
             sampler.idx = idx
             return DeviceDistributedPrefetcher([dev], iter(sampler), pipeline_on=True)
         feeder = EpochFeeder(make_iter, shuffler, get_idx)
-        # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
-        # all of them fall back to the torch.distributed transport together
-        try:
-            native = fs.native_comm() is not None
-            native_err = None
-        except Exception as e:  # noqa: BLE001
-            native, native_err = False, repr(e)
-        flag = torch.tensor([1 if native else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if not int(flag.item()):
-            if native_err and rank == 0:
-                print(f"[bench] native exchange unavailable: {native_err}", file=sys.stderr, flush=True)
-            os.environ["SPP_DIST_TRANSPORT"] = "torch"
-            native = False
         parallelism = f"dp{world}: features range-partitioned {world}-way, {a.cache_strategy} cache " \
                       f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {a.seed_scheme} seeds, {max(1, n_local // bs)} batches per rank and epoch, " + \
                       ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
@@ -517,7 +539,9 @@ def main():
             # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
             # by up to the slot-sets in flight, so this is within one group of the bytes of the K batches)
             sent, recv = xb1[0] - xb0[0], xb1[1] - xb0[1]
-            out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI", "rank0_sent_MB_per_batch": sent / a.steps / 1e6,
+            out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI",
+                               "verified_bit_exact_vs_full_table": exchange_verified,
+                               "rank0_sent_MB_per_batch": sent / a.steps / 1e6,
                                "rank0_received_MB_per_batch": recv / a.steps / 1e6,
                                "rank0_GBps_out": sent / dt / 1e9, "rank0_GBps_in": recv / dt / 1e9,
                                "xgmi_peak_GBps_per_gpu": 7 * 153.0}
