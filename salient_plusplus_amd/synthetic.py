@@ -14,6 +14,9 @@ WORKLOADS = {
     # ogbn-papers100M scale: 111 M nodes, ~3.2 G symmetric nnz (col 25.8 GB int64), F=128 fp16 (28.4 GB)
     "S-papers": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
     "S-papers-uniform": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
+    # MAG240M paper-paper scale (BASELINE.json configs[4]): 121.7 M nodes, ~2.6 G symmetric nnz, F=768 fp16
+    # = 187 GB of features: with the topology it still fits ONE MI355X (288 GB)
+    "S-mag": (121_751_666, 1_297_748_926, 768, 1_112_392, [25, 15], 1024),
 }
 
 # Planted partition locality.  The multi-GPU configurations of BASELINE.json are METIS partitions of
@@ -24,7 +27,7 @@ WORKLOADS = {
 # drawn from the first endpoint's block with probability q (80 % intra-block edges = a 20 % edge cut
 # at 8 parts, less at 4 and 2 since the contiguous range partitions are unions of blocks).
 # "S-papers-uniform" is the same graph without it.  name -> (blocks, q)
-LOCALITY = {"S-papers": (8, 0.8)}
+LOCALITY = {"S-papers": (8, 0.8), "S-mag": (8, 0.8)}
 
 
 MAX_KEYS_PER_SORT = 1 << 30     # torch.unique / CUB take fewer than 2^31 keys per call
@@ -109,6 +112,8 @@ def make_workload(name: str, seed: int = 1234, device=None) -> Workload:
     if device is None:
         device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     rowptr, col = make_graph(N, m, seed, device, LOCALITY.get(name))
+    if torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()      # make room for the feature matrix (187 GB at MAG240 scale)
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1)
     x = torch.empty((N, F), device=device, dtype=torch.float16)
