@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
 // (node, kPending | p) to the bucket's known list for the later hops.
 template <int LDS_LOG2>
 __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                       int32_t h, DedupGeom g, int32_t cb_log2) {
+                                                       int32_t h, DedupGeom g, int32_t cb_log2, int32_t last_hop) {
   __shared__ unsigned long long tab[1 << LDS_LOG2];
   __shared__ int32_t fkc[kMaxFinePerCoarse];   // entries of each fine known list at entry
   __shared__ int32_t fnew[kMaxFinePerCoarse];  // nodes this hop appends to each
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     const uint32_t key = (uint32_t)(pr >> 32), p = (uint32_t)pr;
     const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
     s.evals[p] = val;
-    if (val == T + p) {  // first occurrence of a new node: append to its fine list
+    if (val == T + p && !last_hop) {  // first occurrence of a new node: append to its fine list (no later hop: skip)
       const int32_t lf = (int32_t)bucket_of(key, g.nb_log2) - fb0;
       const int j = fkc[lf] + atomicAdd(&fnew[lf], 1);
       if (j < g.kcap) s.known[(int64_t)(fb0 + lf) * g.kcap + j] = ((unsigned long long)key << 32) | kPending | p;
@@ -1369,14 +1369,15 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
+    const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
     hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
     hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
     if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
+      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
     else if (s->lds_log2 == 13)
-      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
+      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
     else
-      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb);
+      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
     hipLaunchKernelGGL(k_hop_flag, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
     hipLaunchKernelGGL(k_hop_scan2, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f,
                        (int32_t)s->tcap[H]);
