@@ -370,6 +370,10 @@ def main():
         else:
             cache = fs.Cache()
         _trace(f"cache built ({n_cache} rows)")
+        # This benchmark issues no collectives of its own inside the timed loop, so the exchanges may be
+        # issued by the session thread as soon as a group is sampled (most overlap); a training loop with
+        # DDP all-reduces keeps the library default (SPP_EXCHANGE_ISSUE=consumer).
+        os.environ.setdefault("SPP_EXCHANGE_ISSUE", "thread")
         # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
         # all of them fall back to the torch.distributed transport together
         try:
@@ -435,7 +439,8 @@ def main():
         feeder = EpochFeeder(make_iter, shuffler, get_idx)
         parallelism = f"dp{world}: features range-partitioned {world}-way, {a.cache_strategy} cache " \
                       f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {a.seed_scheme} seeds, {max(1, n_local // bs)} batches per rank and epoch, " + \
-                      ("native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows)"
+                      (f"native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows; issued by the "
+                       f"{os.environ.get('SPP_EXCHANGE_ISSUE')})"
                        if native else "torch.distributed all_to_all_single per batch")
 
     # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----

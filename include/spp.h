@@ -340,6 +340,13 @@ typedef struct spp_exchange_cfg {
   int64_t cache_rows;
   int64_t x_local_stride_bytes;    /* distance between rows of x_local / of the cache (0 = dense)    */
   int64_t cache_stride_bytes;
+  int32_t issue_on_consumer;       /* 0: a session thread issues each group's exchange as soon as its
+                                      sampling completes (most overlap).  1: spp_session_next issues it,
+                                      at the same point of the program on every rank (own group when
+                                      needed, the next one from mid-group on) -- use it when the caller
+                                      interleaves collectives of its own communicator, e.g. DDP gradient
+                                      all-reduces: both communicators' kernels are then queued in the
+                                      same order on every rank.                                      */
 } spp_exchange_cfg;
 
 /* BLOCKING: returns when the session's threads have issued everything they can without further

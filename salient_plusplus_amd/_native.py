@@ -43,7 +43,7 @@ class MfgOut(C.Structure):
 class ExchangeCfg(C.Structure):
     _fields_ = [("comm", p), ("x_local_dev", p), ("x_local_rows", i64), ("row_bytes", i64),
                 ("cache_feats_dev", p), ("cache_rows", i64), ("x_local_stride_bytes", i64),
-                ("cache_stride_bytes", i64)]
+                ("cache_stride_bytes", i64), ("issue_on_consumer", i32)]
 
 
 class SessionCfg(C.Structure):

@@ -108,6 +108,7 @@ struct spp_session {
   int64_t rank_offset = 0;
   hipStream_t comm_stream = nullptr;
   std::thread exchanger;
+  bool issue_on_consumer = false;        // exchanges are issued by the consumer thread at fixed program points
   int64_t exchange_launched = 0;         // groups whose exchange was enqueued (guarded by mu)
   spp_status exchange_rc = SPP_OK;
   std::string exchange_err;
@@ -405,6 +406,7 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   SPP_REQUIRE(!part.use_cache || xc->cache_feats_dev || xc->cache_rows == 0,
               "spp_session_create: use_cache without cache rows");
   s->xcfg = *xc;
+  s->issue_on_consumer = xc->issue_on_consumer != 0;
   if (s->xcfg.x_local_stride_bytes <= 0) s->xcfg.x_local_stride_bytes = xc->row_bytes;
   if (s->xcfg.cache_stride_bytes <= 0) s->xcfg.cache_stride_bytes = xc->row_bytes;
   SPP_REQUIRE(s->xcfg.x_local_stride_bytes >= xc->row_bytes && s->xcfg.cache_stride_bytes >= xc->row_bytes,
@@ -546,7 +548,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   if (rc == SPP_OK && cfg->exchange) rc = exchange_setup(s, cfg->exchange, want);
   if (rc == SPP_OK) {
     s->launcher = std::thread(launcher_main, s);  // primes the pipeline right away
-    if (s->tr) s->exchanger = std::thread(exchanger_main, s);
+    if (s->tr && !s->issue_on_consumer) s->exchanger = std::thread(exchanger_main, s);
     if (s->num_groups > 0) rc = wait_group_launched(s, 0);
   }
   if (rc != SPP_OK) {
@@ -608,6 +610,29 @@ static spp_status retire_current(spp_session* s) {
   return SPP_OK;
 }
 
+// Consumer-issued exchanges (spp_exchange_cfg.issue_on_consumer): the exchange of group g is issued
+// from spp_session_next at a fixed point of the program -- when the consumer reaches the middle of
+// group g-1 (or needs group g right now) -- instead of from the session thread as soon as the chain
+// completes.  Every rank then issues its exchanges at the same place relative to the collectives the
+// caller issues on its own process group (e.g. DDP gradient all-reduces), which rules out the
+// opposite-order queueing of two communicators' kernels; the price is less overlap.
+static spp_status issue_exchanges_up_to(spp_session* s, int64_t last_group) {
+  if (last_group >= s->num_groups) last_group = s->num_groups - 1;
+  while (s->exchange_launched <= last_group) {
+    const int64_t g = s->exchange_launched;
+    SPP_TRY(wait_group_launched(s, g));
+    const spp_status rc = exchange_group(s, g);
+    if (rc != SPP_OK) {
+      s->exchange_rc = rc;
+      s->exchange_err = spp_last_error();
+      return rc;
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->exchange_launched = g + 1;
+  }
+  return SPP_OK;
+}
+
 extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   if (!s || !out) {
     set_error("spp_session_next: NULL argument");
@@ -623,6 +648,8 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   const int32_t slot = (int32_t)((g % s->num_sets) * s->G + b % s->G);
   const auto t0 = std::chrono::steady_clock::now();
   spp_status rc = wait_group_launched(s, g);
+  if (rc == SPP_OK && s->tr && s->issue_on_consumer)
+    rc = issue_exchanges_up_to(s, (b % s->G) * 2 >= s->G ? g + 1 : g);  // own group now, the next one from mid-group
   if (rc == SPP_OK) rc = spp_sampler_wait(s->sampler, slot, &out->counts);
   if (rc == SPP_OK && s->tr) rc = wait_group_exchanged(s, g);
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -652,7 +679,7 @@ extern "C" int spp_session_try_next(spp_session* s, spp_batch_desc* out) {
     {
       std::lock_guard<std::mutex> lk(s->mu);
       if (s->launch_rc == SPP_OK && s->exchange_rc == SPP_OK &&
-          (s->chain_launched <= g || (s->tr && s->exchange_launched <= g)))
+          (s->chain_launched <= g || (s->tr && !s->issue_on_consumer && s->exchange_launched <= g)))
         return 2;
     }
     hipEvent_t ev = sampler_slot_event(s->sampler, slot);
@@ -714,8 +741,8 @@ extern "C" spp_status spp_session_quiesce(spp_session* s) {
     s->cv.wait(lk, [s] {
       const int64_t target = std::min<int64_t>(s->num_groups, s->groups_consumed + s->num_sets);
       const bool launcher_idle = s->launch_rc != SPP_OK || s->chain_launched >= target;
-      const bool exchanger_idle = !s->tr || s->exchange_rc != SPP_OK || s->launch_rc != SPP_OK ||
-                                  s->exchange_launched >= target;
+      const bool exchanger_idle = !s->tr || s->issue_on_consumer || s->exchange_rc != SPP_OK ||
+                                  s->launch_rc != SPP_OK || s->exchange_launched >= target;
       return launcher_idle && exchanger_idle;
     });
   }

@@ -509,6 +509,10 @@ class Session:
                 xc.x_local_dev, xc.x_local_rows = self._x.data_ptr(), self._x.size(0)
                 xc.row_bytes = self._x.size(1) * self._x.element_size()
                 xc.x_local_stride_bytes = _stride_bytes(self._x)
+                # who issues the exchanges: a session thread (most overlap) or the consumer inside
+                # blocking_get_batch_distributed, at the same program point on every rank (safe next
+                # to the caller's own collectives, e.g. DDP all-reduces) -- the default
+                xc.issue_on_consumer = int(os.environ.get("SPP_EXCHANGE_ISSUE", "consumer").lower() != "thread")
                 if bool(config.use_cache):
                     self._cache_feats = config.cache.device_features()
                     if self._cache_feats.numel():

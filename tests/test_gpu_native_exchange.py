@@ -111,8 +111,10 @@ def _run_rank(rank, P, comms, g, offsets, use_cache, nb, bs, slots, errors, stat
     (8, True, 9, 8, 32),        # the scaling bench's rank count
     (-2, False, 4, 16, 8),      # degenerate book: rank 0 owns every vertex, rank 1 none (all its rows are remote)
 ])
-def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots):
+@pytest.mark.parametrize("issue", ["thread", "consumer"])
+def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots, issue, monkeypatch):
     from salient_plusplus_amd import fast_sampler as fs
+    monkeypatch.setenv("SPP_EXCHANGE_ISSUE", issue)       # who issues the exchanges: session thread / consumer
     g = _graph()
     n = g["rowptr"].shape[0] - 1
     if P == -2:
