@@ -160,8 +160,9 @@ def test_serial_index_to_row_major_partition_book_cache(fs, graph_a, golden_dir)
     assert empty.cached_vertices.numel() == 0 and empty.cached_features.dtype == torch.float16
 
 
+@pytest.mark.parametrize("sizes", [[15, 10, 5], [3, -1], [40, 2]])      # fast path, all-neighbour hop, fanout > 32
 @pytest.mark.parametrize("P,rank,use_cache", [(2, 0, False), (2, 1, True), (4, 0, True), (4, 1, False), (4, 3, True)])
-def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache):
+def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache, sizes):
     """Worker distributed branch (fast_sampler.cpp:1017-1262) on the GPU vs the oracle's restatement."""
     from oracle import oracle as orc
     from salient_plusplus_amd.fast_trainer.samplers import FastSampler
@@ -179,7 +180,7 @@ def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache):
     else:
         cv, cache, ocache = None, fs.Cache(), None
     G = 100
-    cfg = make_cfg(fs, graph_a, [15, 10, 5], 64, x[lo:hi][G:].copy(), graph_a["y"], graph_a["idx"],
+    cfg = make_cfg(fs, graph_a, sizes, 64, x[lo:hi][G:].copy(), graph_a["y"], graph_a["idx"],
                    x_gpu=T(x[lo:hi][:G].copy()).cuda(), distributed=True,
                    partition_book=fs.RangePartitionBook(rank, P, T(offs)), cache=cache,
                    force_exact_num_batches=True, exact_num_batches=3, use_cache=use_cache)
@@ -188,7 +189,7 @@ def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache):
     for b, proto in enumerate(iter(FastSampler(2, 4, cfg))):
         start, stop = int(ranges[b][0]), int(ranges[b][1])
         assert (proto.idx_range.start, proto.idx_range.stop) == (start, stop)
-        m = orc.sample_batch(graph_a["rowptr"], graph_a["col"], graph_a["idx"], start, stop, [15, 10, 5])
+        m = orc.sample_batch(graph_a["rowptr"], graph_a["col"], graph_a["idx"], start, stop, sizes)
         want = orc.partition_batch(m.n_id, offs, rank, ocache, 0)
         for k in range(P):
             np.testing.assert_array_equal(proto.partition_nids[k].cpu().numpy(), want.partition_nids[k])
