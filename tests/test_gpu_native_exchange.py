@@ -353,3 +353,25 @@ def test_mismatched_batch_counts_are_refused_not_hung():
         c.close()
     assert not any(t.is_alive() for t in ts)
     assert all("same number of batches" in out[r] for r in range(2)), out
+
+
+def test_native_exchange_on_the_generic_sampling_path(monkeypatch):
+    """An all-neighbour hop forces one-batch groups (the generic path sizes launches on the host), so
+    the exchange runs once per batch: same result."""
+    import sys as _sys
+    from salient_plusplus_amd import fast_sampler as fs
+    monkeypatch.setattr(_sys.modules[__name__], "SIZES", [3, -1])
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    comms = fs.NativeComm.local(2)
+    errors, stats = [], {}
+    ts = [threading.Thread(target=_run_rank, args=(r, 2, comms, g, [0, 1400, n], True, 5, 8, 4, errors, stats))
+          for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not any(t.is_alive() for t in ts)
