@@ -317,7 +317,28 @@ static spp_status exchange_group(spp_session* s, int64_t g) {
   SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.send_ids, &xb.send_ids_cap, total_in, 4));
   SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.recv_rows, &xb.recv_rows_cap, total_in, rb));
   if (total_in > 0) SPP_TRY(sampler_pack_remote_ids(s->sampler, set * G, n, x.cnt_dev + ge, xb.send_ids, st));
-  SPP_HIP_TRY(hipEventSynchronize(x.cnt_ready));
+  {
+    // wait for the gathered counts -- i.e. for every peer to reach this group.  A peer that never
+    // arrives (crashed rank, unequal batch counts slipping past the creation-time check) would make
+    // this wait forever: give up with a message after SPP_EXCHANGE_TIMEOUT_S seconds (default 300).
+    static const double limit_s = [] {
+      const char* e = getenv("SPP_EXCHANGE_TIMEOUT_S");
+      const double v = e ? atof(e) : 300.0;
+      return v > 0 ? v : 300.0;
+    }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipEventQuery(x.cnt_ready);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) SPP_HIP_TRY(q);
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+        set_error("exchange of group %lld: rank %d waited %.0f s for its peers' request counts (a rank is missing, or "
+                  "the ranks disagree on the batch sequence)", (long long)g, R, limit_s);
+        return SPP_ERR_STATE;
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  }
   // rows peer m wants from this rank (all batches of the group, in batch order)
   int64_t serve_for[SPP_MAX_PARTS], out_base[SPP_MAX_PARTS];
   int64_t total_req = 0;
