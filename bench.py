@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true",
                     help="skip the (untimed-in-value) SAGE step measurement that gives the epoch-time figure")
     ap.add_argument("--cache-frac", type=float, default=0.10)
+    ap.add_argument("--model", default="sage", choices=["sage", "gat"],
+                    help="consumer model of the epoch-time figure (models.py); the plain-torch comparison is SAGE")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the bit-exact check of one group of batches through the native exchange")
     ap.add_argument("--prime", type=int, default=16,
@@ -108,14 +110,14 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=24, warm=4, hip=True):
+def model_step_timing(feeder, F, n_classes, steps=24, warm=4, hip=True, arch="sage"):
     """ms/step of fwd+bwd+Adam with the data path feeding it, and with one resident batch re-used.
     hip=True: salient_plusplus_amd.models.SAGE (HIP mean aggregation); False: the plain-torch
     formulation above."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if hip:
-        from salient_plusplus_amd.models import SAGE
-        model = SAGE(F, 256, n_classes, 3).to(dev)
+        from salient_plusplus_amd.models import GAT, SAGE
+        model = (GAT if arch == "gat" else SAGE)(F, 256, n_classes, 3).to(dev)
     else:
         model = TorchSAGE(F, 256, n_classes).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -552,11 +554,12 @@ def main():
                                "xgmi_peak_GBps_per_gpu": 7 * 153.0}
         if not a.no_model_step and not distributed:
             try:
-                m_only, m_data = model_step_timing(feeder, F, 47, hip=True)
+                m_only, m_data = model_step_timing(feeder, F, 47, hip=True, arch=a.model)
                 t_only, t_data = model_step_timing(feeder, F, 47, hip=False)
                 nb_epoch = wl.train_idx.numel() // bs
-                out["epoch_time_s_with_sage_step"] = nb_epoch * m_data / 1e3
-                out["model_step"] = {"model": "SAGE 3x256 (models.py: HIP mean aggregation + library GEMMs, fp32, Adam)",
+                out["epoch_time_s_with_model_step"] = nb_epoch * m_data / 1e3
+                out["model_step"] = {"model": f"{a.model.upper()} 3x256 (models.py: HIP message passing + library GEMMs, "
+                                              f"fp32, Adam)",
                                      "ms_per_step_model_only_resident_batch": m_only,
                                      "ms_per_step_with_data_path": m_data,
                                      "plain_torch_formulation": {"ms_per_step_model_only_resident_batch": t_only,
