@@ -9,7 +9,7 @@ import torch  # noqa: E402
 from salient_plusplus_amd import fast_sampler as fs  # noqa: E402
 from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig  # noqa: E402
 from salient_plusplus_amd.fast_trainer.transferers import DevicePrefetcher  # noqa: E402
-from salient_plusplus_amd.models import SAGE  # noqa: E402
+from salient_plusplus_amd.models import GAT, SAGE  # noqa: E402
 from salient_plusplus_amd.synthetic import make_workload  # noqa: E402
 
 dev = torch.device("cuda", 0)
@@ -21,7 +21,7 @@ cfg = FastSamplerConfig(
     count_remote_frequency=False, use_cache=False)
 (b,) = next(iter(DevicePrefetcher([dev], iter(FastSampler(2, 8, cfg)))))
 torch.cuda.synchronize()
-model = SAGE(wl.x.size(1), 256, 47, 3).to(dev)
+model = (GAT if os.environ.get('MODEL') == 'gat' else SAGE)(wl.x.size(1), 256, 47, 3).to(dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 print("batch:", b.x.shape, [tuple(a.size) for a in b.adjs], flush=True)
 for _ in range(int(os.environ.get("STEPS", "20"))):
