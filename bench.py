@@ -443,7 +443,7 @@ def main():
                       f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {a.seed_scheme} seeds, {max(1, n_local // bs)} batches per rank and epoch, " + \
                       (f"native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows; issued by the "
                        f"{os.environ.get('SPP_EXCHANGE_ISSUE')})"
-                       if native else "torch.distributed all_to_all_single per batch")
+                       if native else "torch.distributed all_to_all_single, one exchange per group of 8 batches")
 
     # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----
     _trace("iterator ready, priming")

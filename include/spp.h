@@ -225,8 +225,11 @@ spp_status spp_assemble_features(const int64_t* n_id_dev, const int64_t* perm_de
                                  const void* recv_dev, const void* cache_feats_dev,
                                  const int64_t* cached_nids_dev, int64_t row_bytes,
                                  int64_t x_local_stride_bytes /* 0 = dense */,
-                                 int64_t cache_stride_bytes /* 0 = dense */, void* x_out_dev,
-                                 void* stream);
+                                 int64_t cache_stride_bytes /* 0 = dense */,
+                                 const int64_t* recv_base_host /* int64[P] or NULL: row of recv_dev where
+                                    peer m's rows for this batch start, when recv_dev holds the rows of
+                                    several batches (one exchange per group) */,
+                                 void* x_out_dev, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * a6/a7  Session runtime (fast_sampler.cpp:533-936 Session, :963-1016 worker,
@@ -300,6 +303,8 @@ spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
  * (fast_sampler.cpp:788-799 total_blocked_dur / total_blocked_occasions) */
 int64_t spp_session_blocked_us(const spp_session* s);
 int64_t spp_session_blocked_occasions(const spp_session* s);
+/* batches per sampling group (they become ready together; exchanges are per group) */
+int32_t spp_session_group_size(const spp_session* s);
 /* the sampler owned by the session (for spp_sampler_gather on the current slot etc.) */
 spp_sampler* spp_session_sampler(spp_session* s);
 

@@ -86,7 +86,7 @@ SIGNATURES = {
     "spp_cache_lookup": (C.c_int, [p, i64, p, i64, p, p, p]),
     "spp_partition_workspace_bytes": (i64, [i64]),
     "spp_partition_batch": (C.c_int, [p, i64, p, i32, i32, i32, p, i64, i64, p, p, p, p, p, p, i64, p]),
-    "spp_assemble_features": (C.c_int, [p, p, i64, p, i32, i32, i64, p, i64, p, p, p, i64, i64, i64, p, p]),
+    "spp_assemble_features": (C.c_int, [p, p, i64, p, i32, i32, i64, p, i64, p, p, p, i64, i64, i64, p, p, p]),
     "spp_session_create": (C.c_int, [C.POINTER(SessionCfg), C.POINTER(p)]),
     "spp_session_destroy": (None, [p]),
     "spp_session_num_total_batches": (i64, [p]),
@@ -97,6 +97,7 @@ SIGNATURES = {
     "spp_session_blocked_us": (i64, [p]),
     "spp_session_blocked_occasions": (i64, [p]),
     "spp_session_sampler": (p, [p]),
+    "spp_session_group_size": (i32, [p]),
     "spp_comm_unique_id": (C.c_int, [p]),
     "spp_comm_create": (C.c_int, [p, i32, i32, i32, C.POINTER(p)]),
     "spp_comm_create_local": (C.c_int, [i32, i32, C.POINTER(p)]),

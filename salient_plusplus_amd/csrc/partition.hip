@@ -309,7 +309,8 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
                                             const void* x_local_dev, int64_t x_local_rows, const void* recv_dev,
                                             const void* cache_feats_dev, const int64_t* cached_nids_dev,
                                             int64_t row_bytes, int64_t x_local_stride_bytes,
-                                            int64_t cache_stride_bytes, void* x_out_dev, void* stream) {
+                                            int64_t cache_stride_bytes, const int64_t* recv_base_host,
+                                            void* x_out_dev, void* stream) {
   SPP_REQUIRE(P >= 1 && P <= SPP_MAX_PARTS && rank >= 0 && rank < P, "spp_assemble_features: bad P/rank");
   SPP_REQUIRE(seg_start_host, "spp_assemble_features: seg_start_host is NULL");
   if (U <= 0 || row_bytes <= 0) return SPP_OK;
@@ -323,7 +324,7 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
   int64_t rb = 0;
   for (int m = 0; m <= P + 1; ++m) a.seg_start[m] = seg_start_host[m];
   for (int m = 0; m < P; ++m) {
-    a.recv_base[m] = rb;
+    a.recv_base[m] = recv_base_host ? recv_base_host[m] : rb;  // explicit: rows of a whole GROUP in one buffer
     if (m != rank) rb += seg_start_host[m + 1] - seg_start_host[m];
   }
   SPP_REQUIRE(seg_start_host[P + 1] == U, "spp_assemble_features: segments (%lld) do not cover U (%lld)",

@@ -610,6 +610,7 @@ extern "C" int64_t spp_session_num_consumed_batches(const spp_session* s) { retu
 extern "C" int64_t spp_session_blocked_us(const spp_session* s) { return s ? s->blocked_us : 0; }
 extern "C" int64_t spp_session_blocked_occasions(const spp_session* s) { return s ? s->blocked_occasions : 0; }
 extern "C" spp_sampler* spp_session_sampler(spp_session* s) { return s ? s->sampler : nullptr; }
+extern "C" int32_t spp_session_group_size(const spp_session* s) { return s ? s->G : 0; }
 
 extern "C" spp_status spp_session_batch_ranges(const spp_session* s, int32_t* out) {
   SPP_REQUIRE(s && out, "spp_session_batch_ranges: NULL argument");

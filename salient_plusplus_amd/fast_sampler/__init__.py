@@ -611,6 +611,11 @@ class Session:
         return int(self._L.spp_session_num_consumed_batches(self._h))
 
     @property
+    def group_size(self) -> int:
+        """batches sampled (and, in distributed mode, exchanged) together"""
+        return int(self._L.spp_session_group_size(self._h))
+
+    @property
     def approx_num_complete_batches(self) -> int:
         return self.num_consumed_batches
 

@@ -79,14 +79,17 @@ class _HipFeatureOps:
         return out
 
     def assemble(self, n_id, perm, seg_start: List[int], P: int, rank: int, rank_offset: int, x_local, recv,
-                 cache_feats, cached_nids) -> torch.Tensor:
+                 cache_feats, cached_nids, recv_base: Optional[List[int]] = None) -> torch.Tensor:
+        """recv_base[m]: row of `recv` where peer m's rows for THIS batch start (None: rows packed in
+        partition order with the own segment absent)"""
         U = n_id.numel()
         out = torch.empty((U, x_local.size(1)), dtype=x_local.dtype, device=x_local.device)
         seg = (C.c_int64 * (P + 2))(*seg_start)
+        base = (C.c_int64 * P)(*recv_base) if recv_base is not None else None
         self.nat.check(self.L.spp_assemble_features(
             self._p(n_id), self._p(perm), U, seg, P, rank, rank_offset, self._p(x_local), x_local.size(0),
             self._p(recv), self._p(cache_feats), self._p(cached_nids), x_local.size(1) * x_local.element_size(),
-            self._row_stride(x_local), self._row_stride(cache_feats), self._p(out), self._stream()))
+            self._row_stride(x_local), self._row_stride(cache_feats), base, self._p(out), self._stream()))
         return out
 
 
@@ -151,119 +154,142 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         # the sampler's persistent delivery stream when there is one, default priority (see DevicePrefetcher)
         self.side = _SideStream(self.device, stream=getattr(self.it.session, "consumer_stream", None)
                                 if _is_cuda(self.device) else None)
+        # torch.distributed transport: ONE exchange (three collectives) per GROUP of batches -- the
+        # batches of a sampler group become ready together, and a collective call costs ~80 us of host
+        # time in c10d whatever its size
+        self.G = max(1, int(getattr(self.it.session, "group_size", 1)))
         if self.side.cuda:
             self.counts_stream = torch.cuda.Stream(self.device)
             ring = 8               # > pipeline depth: a pinned buffer is reused only after its copy ran
-            self._sc_pinned = [torch.empty(self.world_size, dtype=torch.int64).pin_memory() for _ in range(ring)]
-            self._rc_pinned = [torch.empty(self.world_size, dtype=torch.int64).pin_memory() for _ in range(ring)]
+            n_cnt = self.world_size * self.G
+            self._sc_pinned = [torch.empty(n_cnt, dtype=torch.int64).pin_memory() for _ in range(ring)]
+            self._rc_pinned = [torch.empty(n_cnt, dtype=torch.int64).pin_memory() for _ in range(ring)]
             self._ring_pos = 0
-        self.q_counts = deque()    # batches whose counts exchange is in flight
-        self.q_rows = deque()      # batches whose row exchange is in flight
+        self.q_counts = deque()    # groups whose counts exchange is in flight
+        self.q_rows = deque()      # groups whose row exchange is in flight
+        self.ready = deque()       # assembled batches of the current group
         self.next: Optional[list] = []
         self.NUMBER_OF_SENT_BYTES = 0
         self.ITERATION = 0
         self._exhausted = False
-        depth = 2 if (pipeline_on and not self.native) else 0
-        for _ in range(depth):
-            self._advance(produce_output=False)
-        self._advance(produce_output=True)
+        if self.native:
+            self._advance(produce_output=True)
+        else:
+            for _ in range(2 if pipeline_on else 0):
+                self._advance(produce_output=False)
+            self._fill_next()
 
-    # ---- stages ----
+    # ---- stages of the torch.distributed transport (one pass per group) ----
     def _stage_sample_and_counts(self):
-        if self._exhausted:
-            return
+        """pull the next group of sampled batches and start the exchange of their request counts (C1)"""
+        protos = []
         runtime_stats_cuda.start_region("sampling2")
-        proto = next(self.it, None)
+        while len(protos) < self.G and not self._exhausted:
+            proto = next(self.it, None)
+            if proto is None:
+                self._exhausted = True
+            else:
+                protos.append(proto)
         runtime_stats_cuda.end_region("sampling2")
-        if proto is None:
-            self._exhausted = True
+        if not protos:
             return
-        P = self.world_size
-        send_counts = [int(p.numel()) for p in proto.partition_nids]
-        dev = proto.perm_partition_to_mfg.device
+        P, r, G = self.world_size, self.rank, self.G
+        cnt = [[int(t.numel()) for t in p.partition_nids] for p in protos]     # [batch][owner]
+        mat = torch.zeros((P, G), dtype=torch.int64)                           # row m: what I ask of peer m, per batch
+        for i, c in enumerate(cnt):
+            for m in range(P):
+                if m != r:
+                    mat[m, i] = c[m]
+        dev = protos[0].perm_partition_to_mfg.device
         if self.side.cuda:
             # The counts exchange runs on a stream of its own and lands in pinned memory behind an
             # event: the host later waits for THIS exchange only, not for the feature assembly that
-            # is queued on the delivery stream (a `.cpu()` there cost ~85 us per batch).
+            # is queued on the delivery stream.
             k = self._ring_pos
             self._ring_pos = (k + 1) % len(self._sc_pinned)
             sc_host, rc_host = self._sc_pinned[k], self._rc_pinned[k]
-            sc_host.copy_(torch.tensor(send_counts, dtype=torch.int64))
+            sc_host.copy_(mat.view(-1))
             with torch.cuda.stream(self.counts_stream):
                 sc = sc_host.to(dev, non_blocking=True)
-                rc = torch.empty(P, dtype=torch.int64, device=dev)
-                h = dist.all_to_all_single(rc, sc, group=self.group, async_op=True)      # C1
+                rc = torch.empty(P * G, dtype=torch.int64, device=dev)
+                h = dist.all_to_all_single(rc, sc, group=self.group, async_op=True)      # C1 (G counts per peer)
                 h.wait()
                 rc_host.copy_(rc, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-            self.q_counts.append((proto, send_counts, sc, rc, (ev, rc_host)))
+            self.q_counts.append((protos, cnt, sc, rc, (ev, rc_host)))
         else:
-            sc = torch.tensor(send_counts, dtype=torch.int64)
-            rc = torch.empty(P, dtype=torch.int64, device=dev)
+            sc = mat.view(-1).clone()
+            rc = torch.empty(P * G, dtype=torch.int64, device=dev)
             h = dist.all_to_all_single(rc, sc, group=self.group, async_op=True)          # C1
-            self.q_counts.append((proto, send_counts, sc, rc, h))
+            self.q_counts.append((protos, cnt, sc, rc, h))
 
     def _stage_ids_serve_rows(self):
+        """exchange the requested node ids (C2), gather the rows the peers asked for, exchange them (C3)"""
         if not self.q_counts:
             return
-        proto, send_counts, sc, rc, h = self.q_counts.popleft()
-        P, r = self.world_size, self.rank
+        protos, cnt, sc, rc, h = self.q_counts.popleft()
+        P, r, G = self.world_size, self.rank, self.G
         if isinstance(h, tuple):
             ev, rc_host = h
             ev.synchronize()
-            recv_counts = [int(v) for v in rc_host.tolist()]
+            asked = rc_host.view(P, G).tolist()            # asked[m][i]: rows peer m wants from me for its batch i
         else:
             h.wait()
-            recv_counts = [int(v) for v in rc.tolist()]
-        dev = proto.perm_partition_to_mfg.device
-        send_ids = getattr(proto, "partition_nids_flat", None)     # the GPU sampler's buckets are one buffer
-        if send_ids is None:
-            send_ids = torch.cat(proto.partition_nids) if len(proto.partition_nids) > 1 else proto.partition_nids[0]
-        recv_ids = torch.empty(sum(recv_counts), dtype=torch.int64, device=dev)
-        h_ids = dist.all_to_all_single(recv_ids, send_ids, output_split_sizes=recv_counts,
-                                       input_split_sizes=send_counts, group=self.group, async_op=True)   # C2
+            asked = rc.view(P, G).tolist()
+        dev = protos[0].perm_partition_to_mfg.device
+        want = [sum(c[m] for c in cnt) if m != r else 0 for m in range(P)]          # ids out to / rows in from peer m
+        serve = [int(sum(asked[m])) if m != r else 0 for m in range(P)]             # ids in from / rows out to peer m
+        pieces = [p.partition_nids[m] for m in range(P) if m != r for p in protos]  # peer-major, then batch
+        send_ids = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.int64, device=dev)
+        recv_ids = torch.empty(sum(serve), dtype=torch.int64, device=dev)
+        h_ids = dist.all_to_all_single(recv_ids, send_ids, output_split_sizes=serve, input_split_sizes=want,
+                                       group=self.group, async_op=True)                                   # C2
         h_ids.wait()
-        # serve: rows requested by the peers (own request is satisfied locally in the assembly)
-        own_lo = sum(recv_counts[:r])
-        own_hi = own_lo + recv_counts[r]
-        peer_ids = torch.cat([recv_ids[:own_lo], recv_ids[own_hi:]]) if P > 1 else recv_ids[:0]
-        send_rows = self.ops.gather_rows(self.features, peer_ids - self.rank_offset)
-        in_splits = [c if m != r else 0 for m, c in enumerate(recv_counts)]
-        out_splits = [c if m != r else 0 for m, c in enumerate(send_counts)]
-        recv_rows = torch.empty((sum(out_splits), self.feature_dim), dtype=self.features_dtype, device=dev)
-        h_rows = dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=out_splits,
-                                        input_split_sizes=in_splits, group=self.group, async_op=True)   # C3
-        self.NUMBER_OF_SENT_BYTES += sum(in_splits) * self.feature_dim * self.features.element_size() \
-            + sum(out_splits) * 8 + 8 * P
+        send_rows = self.ops.gather_rows(self.features, recv_ids - self.rank_offset)
+        recv_rows = torch.empty((sum(want), self.feature_dim), dtype=self.features_dtype, device=dev)
+        h_rows = dist.all_to_all_single(recv_rows, send_rows, output_split_sizes=want, input_split_sizes=serve,
+                                        group=self.group, async_op=True)                                  # C3
+        self.NUMBER_OF_SENT_BYTES += sum(serve) * self.feature_dim * self.features.element_size() \
+            + sum(want) * 8 + 8 * P * G
         for t in (send_ids, recv_ids, send_rows, recv_rows, sc, rc):
             if t.is_cuda and self.side.cuda:
                 t.record_stream(self.side.stream)
-        self.q_rows.append((proto, send_counts, recv_rows, send_rows, h_rows))
+        self.q_rows.append((protos, cnt, want, recv_rows, send_rows, h_rows))
 
     def _stage_assemble(self):
+        """x of every batch of the oldest exchanged group, in MFG order -> self.ready"""
         if not self.q_rows:
-            self.next = None
             return
-        proto, send_counts, recv_rows, _send_rows, h_rows = self.q_rows.popleft()
+        protos, cnt, want, recv_rows, _send_rows, h_rows = self.q_rows.popleft()
         h_rows.wait()
         P, r = self.world_size, self.rank
-        seg = [0]
-        for m in range(P):
-            seg.append(seg[-1] + send_counts[m])
-        seg.append(seg[-1] + int(proto.cached_nids.numel()))
-        n_id = proto.n_id
-        if n_id is None:      # reference-style producer: rebuild the MFG order from the concat + perm
-            ids = torch.cat(list(proto.partition_nids) +
-                            ([self.cache.cached_vertices.to(proto.cached_nids.device)[proto.cached_nids]]
-                             if self.use_cache else []))
-            n_id = ids[proto.perm_partition_to_mfg]
-        x = self.ops.assemble(n_id, proto.perm_partition_to_mfg, seg, P, r, self.rank_offset, self.features,
-                              recv_rows, self.cache_feats, proto.cached_nids)
-        y = proto.sliced_cpu_labels
-        if y is not None and _is_cuda(self.device) and not y.is_cuda:
-            y = y.to(self.device, non_blocking=True)
-        self.next = [PreparedBatch(x, y, proto.adjs, proto.idx_range)]
+        peer_start, acc = [], 0
+        for m in range(P):                     # rows from peer m: one span, its batches in order
+            peer_start.append(acc)
+            acc += want[m]
+        used = [0] * P
+        for proto, c in zip(protos, cnt):
+            seg = [0]
+            for m in range(P):
+                seg.append(seg[-1] + c[m])
+            seg.append(seg[-1] + int(proto.cached_nids.numel()))
+            recv_base = [peer_start[m] + used[m] for m in range(P)]
+            for m in range(P):
+                if m != r:
+                    used[m] += c[m]
+            n_id = proto.n_id
+            if n_id is None:      # reference-style producer: rebuild the MFG order from the concat + perm
+                ids = torch.cat(list(proto.partition_nids) +
+                                ([self.cache.cached_vertices.to(proto.cached_nids.device)[proto.cached_nids]]
+                                 if self.use_cache else []))
+                n_id = ids[proto.perm_partition_to_mfg]
+            x = self.ops.assemble(n_id, proto.perm_partition_to_mfg, seg, P, r, self.rank_offset, self.features,
+                                  recv_rows, self.cache_feats, proto.cached_nids, recv_base)
+            y = proto.sliced_cpu_labels
+            if y is not None and _is_cuda(self.device) and not y.is_cuda:
+                y = y.to(self.device, non_blocking=True)
+            self.ready.append(PreparedBatch(x, y, proto.adjs, proto.idx_range))
 
     def _advance(self, produce_output: bool):
         if self.native:
@@ -280,6 +306,8 @@ class DeviceDistributedPrefetcher(DeviceIterator):
                 else:
                     self.next = [PreparedBatch(proto.x, proto.sliced_cpu_labels, proto.adjs, proto.idx_range)]
             return
+        # one pipeline step at GROUP granularity: assemble the oldest exchanged group, run the id/row
+        # exchange of the next one, start the counts exchange of the one after
         with self.side:
             if produce_output:
                 runtime_stats_cuda.start_region("stage_combine_features")
@@ -287,10 +315,12 @@ class DeviceDistributedPrefetcher(DeviceIterator):
                 runtime_stats_cuda.end_region("stage_combine_features")
             self._stage_ids_serve_rows()
             self._stage_sample_and_counts()
-            if not self.pipeline_on and produce_output and self.next is None and (self.q_counts or self.q_rows):
-                # unpipelined mode: run the freshly sampled batch through all stages now
-                self._stage_ids_serve_rows()
-                self._stage_assemble()
+
+    def _fill_next(self):
+        """torch transport: the next batch to hand out, advancing the group pipeline when needed"""
+        while not self.ready and (self.q_counts or self.q_rows or not self._exhausted):
+            self._advance(produce_output=True)
+        self.next = [self.ready.popleft()] if self.ready else None
 
     def __next__(self):
         ret = self.next
@@ -308,7 +338,10 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         if self.side.cuda:
             for b in ret:
                 b.record_stream(torch.cuda.current_stream(self.device))
-        self._advance(produce_output=True)
+        if self.native:
+            self._advance(produce_output=True)
+        else:
+            self._fill_next()
         return ret
 
     def print_stats(self):

@@ -28,7 +28,8 @@ class OracleOps:
         from oracle import oracle as orc
         return torch.from_numpy(orc.serial_index(x.numpy(), idx.numpy()))
 
-    def assemble(self, n_id, perm, seg_start, P_, rank, rank_offset, x_local, recv, cache_feats, cached_nids):
+    def assemble(self, n_id, perm, seg_start, P_, rank, rank_offset, x_local, recv, cache_feats, cached_nids,
+                 recv_base=None):
         # transferers.py:472-486: x = cat(features_gather + [cached])[perm]
         parts = []
         recv_at = 0
@@ -38,7 +39,8 @@ class OracleOps:
             if m == rank:
                 parts.append(None)
             else:
-                parts.append(recv[recv_at:recv_at + n])
+                at = recv_base[m] if recv_base is not None else recv_at    # rows of a whole group in one buffer
+                parts.append(recv[at:at + n])
                 recv_at += n
         # the own segment: local rows of the nodes whose perm falls into it, in segment order
         inv = torch.empty_like(perm)
@@ -73,7 +75,7 @@ class OracleProtoIter:
     """Stands in for FastSamplerIter in distributed mode: yields ProtoDistributedBatch records
     computed by the oracle (fast_sampler.cpp:1017-1262 restated in oracle/spp_oracle.c)."""
 
-    def __init__(self, g, rank, offsets, use_cache, cv, n_batches):
+    def __init__(self, g, rank, offsets, use_cache, cv, n_batches, group_size=1):
         from oracle import oracle as orc
         from salient_plusplus_amd.fast_trainer.samplers import Adj__from_fast_sampler, ProtoDistributedBatch
         self.orc, self.Adj, self.Proto = orc, Adj__from_fast_sampler, ProtoDistributedBatch
@@ -96,6 +98,7 @@ class OracleProtoIter:
         cfg.x_cpu = x[:0]
         self.session = _StubSession()
         self.session.config = cfg
+        self.session.group_size = group_size        # batches exchanged together (one set of collectives per group)
         self.expected = []
 
     def __iter__(self):
@@ -121,7 +124,7 @@ class OracleProtoIter:
                           idx_range=slice(start, stop), n_id=T(m.n_id))
 
 
-def _worker(rank, port, use_cache, pipeline_on, n_batches, fail_q):
+def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -135,7 +138,7 @@ def _worker(rank, port, use_cache, pipeline_on, n_batches, fail_q):
         rng = np.random.default_rng(100 + rank)
         remote = np.setdiff1d(np.arange(n), np.arange(lo, hi))
         cv = np.sort(rng.choice(remote, size=250, replace=False)).astype(np.int64)
-        it = OracleProtoIter(g, rank, offsets, use_cache, cv, n_batches)
+        it = OracleProtoIter(g, rank, offsets, use_cache, cv, n_batches, group_size)
         devit = DeviceDistributedPrefetcher([torch.device("cpu")], it, pipeline_on, ops=OracleOps())
         got = 0
         for (batch,) in devit:
@@ -157,13 +160,17 @@ def _worker(rank, port, use_cache, pipeline_on, n_batches, fail_q):
         raise
 
 
-@pytest.mark.parametrize("use_cache,pipeline_on,n_batches", [(False, True, 4), (True, True, 3), (True, False, 2),
-                                                             (False, True, 1)])
-def test_distributed_prefetcher_two_ranks_gloo(use_cache, pipeline_on, n_batches):
+@pytest.mark.parametrize("use_cache,pipeline_on,n_batches,group_size", [
+    (False, True, 4, 1), (True, True, 3, 1), (True, False, 2, 1), (False, True, 1, 1),
+    (True, True, 7, 3),      # groups of 3 with a ragged tail: one exchange per group
+    (False, False, 5, 2), (True, True, 4, 8),   # unpipelined groups; a group larger than the epoch
+])
+def test_distributed_prefetcher_two_ranks_gloo(use_cache, pipeline_on, n_batches, group_size):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29650 + (hash((use_cache, pipeline_on, n_batches)) % 200)
-    procs = [ctx.Process(target=_worker, args=(r, port, use_cache, pipeline_on, n_batches, q)) for r in range(P)]
+    port = 29650 + (7 * n_batches + 31 * group_size + 3 * int(use_cache) + int(pipeline_on)) % 200
+    procs = [ctx.Process(target=_worker, args=(r, port, use_cache, pipeline_on, n_batches, group_size, q))
+             for r in range(P)]
     for p in procs:
         p.start()
     for p in procs:
