@@ -723,10 +723,22 @@ __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__
   for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
   __syncthreads();
   const int32_t i = blockIdx.x * kNT + threadIdx.x;
-  if (i < U) {
-    const int32_t b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)s.n_ids[i]);
+  const bool valid = i < U;
+  int32_t b = -1;
+  if (valid) {
+    b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)s.n_ids[i]);
     s.pbucket[i] = (uint8_t)b;
-    atomicAdd(&cnt[b], 1);
+  }
+  // one LDS atomic per (wavefront, bucket present in it) instead of one per node: most nodes of a
+  // wavefront share an owner, and 64 lanes hammering one counter serialise
+  unsigned long long todo = __ballot(valid);
+  const int lane = threadIdx.x & (kWave - 1);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int32_t lb = __shfl(b, leader, kWave);
+    const unsigned long long m = __ballot(valid && b == lb);
+    if (lane == leader) atomicAdd(&cnt[lb], __popcll(m));
+    todo &= ~m;
   }
   __syncthreads();
   for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + blockIdx.x] = cnt[k];
