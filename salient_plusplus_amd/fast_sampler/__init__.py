@@ -498,6 +498,14 @@ class Session:
         if self._part is not None:
             cfg.part = C.pointer(self._part[0])
         self.native_exchange = False
+        # Native exchange and the batch record.  A consumer built on the REFERENCE's façade wraps every
+        # batch in its own 7-field NamedTuple (fast_trainer/samplers.py:32-88), which reads
+        # partition_nids / cached_nids / perm_partition_to_mfg and has no room for `x`: by default the
+        # record therefore carries the ownership buckets as well, and the assembled features stay
+        # retrievable from the Session (take_native_features).  This repository's own façade sets
+        # compact_native_records and gets only what its iterator reads (x, y, MFG).
+        self.compact_native_records = False
+        self._native_feats = {}
         self._cache_feats = None
         if self._distributed:
             comm = native_comm()
@@ -761,12 +769,14 @@ class Session:
         """The exchange already ran natively (session.hip): one launch delivers the MFG, the labels
         and x assembled from {local partition, rows received over RCCL, VIP cache}."""
         cfg = self.config
-        want_parts = bool(cfg.count_remote_frequency) and not use_cache
+        count_remote = bool(cfg.count_remote_frequency) and not use_cache
+        want_parts = count_remote or not self.compact_native_records
         if want_parts:
             out, n_id, adjs, (nids, cached, perm, flat) = self._alloc_mfg(c, num_parts=P)
         else:
             out, n_id, adjs = self._alloc_mfg(c)
-            nids, cached, perm, flat = [], None, None, None
+            nids, flat = [], None
+            cached = perm = torch.empty(0, dtype=torch.int64, device=self._dev)
         x = torch.empty((c.num_nodes, self._x.size(1)), dtype=self._x.dtype, device=self._dev)
         y = None
         if self._y is not None:
@@ -788,9 +798,22 @@ class Session:
         b.adjs = adjs
         b.idx_range = (int(d.start), int(d.stop))
         b.n_id = n_id
-        if want_parts:
+        if count_remote:
             self._count_remote(b.partition_nids, rank)
+        if not self.compact_native_records:
+            # at most the two newest batches (double buffering); a consumer that never asks loses nothing
+            while len(self._native_feats) >= 2:
+                self._native_feats.pop(next(iter(self._native_feats)))
+            self._native_feats[b.idx_range] = (x, n_id)
         return b
+
+    def take_native_features(self, idx_range):
+        """(x, n_id) of the batch covering seeds idx_range = (start, stop) or slice(start, stop), when the
+        exchange ran natively and the consumer's record has no field for them (the reference's
+        ProtoDistributedBatch, fast_trainer/samplers.py:32-68); None when unknown."""
+        if isinstance(idx_range, slice):
+            idx_range = (idx_range.start, idx_range.stop)
+        return self._native_feats.pop((int(idx_range[0]), int(idx_range[1])), None)
 
     def quiesce(self):
         """Block until the session has nothing more to issue without further consumption and its GPU

@@ -244,6 +244,9 @@ class FastSamplerIter(Iterator[PreparedBatch]):
 
     def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig):
         self.session = fast_sampler.Session(num_threads, max_items_in_queue, cfg.to_fast_sampler())
+        # this façade's records have fields for the assembled features and the MFG ids: the native
+        # exchange need not also export the ownership buckets a reference-shaped record would read
+        self.session.compact_native_records = True
         expected = cfg.get_num_batches()
         if self.session.num_total_batches != expected:
             raise AssertionError(f"session plans {self.session.num_total_batches} batches, the configuration {expected}")

@@ -278,10 +278,10 @@ class DeviceDistributedPrefetcher(DeviceIterator):
             for m in range(P):
                 if m != r:
                     used[m] += c[m]
-            n_id = proto.n_id
-            if n_id is None:      # reference-style producer: rebuild the MFG order from the concat + perm
+            n_id = getattr(proto, "n_id", None)
+            if n_id is None:      # reference-shaped record (7 fields): rebuild the MFG order from the concat + perm
                 ids = torch.cat(list(proto.partition_nids) +
-                                ([self.cache.cached_vertices.to(proto.cached_nids.device)[proto.cached_nids]]
+                                ([self._cached_vertices(proto.cached_nids.device)[proto.cached_nids]]
                                  if self.use_cache else []))
                 n_id = ids[proto.perm_partition_to_mfg]
             x = self.ops.assemble(n_id, proto.perm_partition_to_mfg, seg, P, r, self.rank_offset, self.features,
@@ -290,6 +290,13 @@ class DeviceDistributedPrefetcher(DeviceIterator):
             if y is not None and _is_cuda(self.device) and not y.is_cuda:
                 y = y.to(self.device, non_blocking=True)
             self.ready.append(PreparedBatch(x, y, proto.adjs, proto.idx_range))
+
+    def _cached_vertices(self, device):
+        """global ids of the cache's rows on `device` (uploaded once)"""
+        cv = getattr(self, "_cv_dev", None)
+        if cv is None or cv.device != device:
+            cv = self._cv_dev = self.cache.cached_vertices.to(device)
+        return cv
 
     def _advance(self, produce_output: bool):
         if self.native:
@@ -304,7 +311,16 @@ class DeviceDistributedPrefetcher(DeviceIterator):
                     sent, _recv = self.it.session.exchange_bytes()
                     self.NUMBER_OF_SENT_BYTES = sent
                 else:
-                    self.next = [PreparedBatch(proto.x, proto.sliced_cpu_labels, proto.adjs, proto.idx_range)]
+                    x = getattr(proto, "x", None)
+                    if x is None:
+                        # the reference's own ProtoDistributedBatch (fast_trainer/samplers.py:32-68) has no
+                        # field for the assembled features: the Session kept them for this batch
+                        kept = self.it.session.take_native_features(proto.idx_range)
+                        if kept is None:
+                            raise RuntimeError("native exchange: the batch record carries no x and the Session "
+                                               f"holds none for seeds {proto.idx_range}")
+                        x = kept[0]
+                    self.next = [PreparedBatch(x, proto.sliced_cpu_labels, proto.adjs, proto.idx_range)]
             return
         # one pipeline step at GROUP granularity: assemble the oldest exchanged group, run the id/row
         # exchange of the next one, start the counts exchange of the one after

@@ -75,10 +75,15 @@ class OracleProtoIter:
     """Stands in for FastSamplerIter in distributed mode: yields ProtoDistributedBatch records
     computed by the oracle (fast_sampler.cpp:1017-1262 restated in oracle/spp_oracle.c)."""
 
-    def __init__(self, g, rank, offsets, use_cache, cv, n_batches, group_size=1):
+    def __init__(self, g, rank, offsets, use_cache, cv, n_batches, group_size=1, ref_shaped=False):
         from oracle import oracle as orc
         from salient_plusplus_amd.fast_trainer.samplers import Adj__from_fast_sampler, ProtoDistributedBatch
         self.orc, self.Adj, self.Proto = orc, Adj__from_fast_sampler, ProtoDistributedBatch
+        if ref_shaped:
+            # the reference's own record (fast_trainer/samplers.py:32-68): seven fields, no n_id / x
+            import collections
+            ref = collections.namedtuple("RefShapedProto", ProtoDistributedBatch._fields[:7])
+            self.Proto = lambda n_id=None, **kw: ref(**kw)      # noqa: E731
         self.g, self.rank, self.offsets = g, rank, offsets
         n = g["rowptr"].shape[0] - 1
         self.ocache = orc.Cache(cv, n) if use_cache else None
@@ -124,7 +129,7 @@ class OracleProtoIter:
                           idx_range=slice(start, stop), n_id=T(m.n_id))
 
 
-def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q):
+def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q, ref_shaped=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -138,7 +143,7 @@ def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q):
         rng = np.random.default_rng(100 + rank)
         remote = np.setdiff1d(np.arange(n), np.arange(lo, hi))
         cv = np.sort(rng.choice(remote, size=250, replace=False)).astype(np.int64)
-        it = OracleProtoIter(g, rank, offsets, use_cache, cv, n_batches, group_size)
+        it = OracleProtoIter(g, rank, offsets, use_cache, cv, n_batches, group_size, ref_shaped)
         devit = DeviceDistributedPrefetcher([torch.device("cpu")], it, pipeline_on, ops=OracleOps())
         got = 0
         for (batch,) in devit:
@@ -160,16 +165,17 @@ def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q):
         raise
 
 
-@pytest.mark.parametrize("use_cache,pipeline_on,n_batches,group_size", [
-    (False, True, 4, 1), (True, True, 3, 1), (True, False, 2, 1), (False, True, 1, 1),
-    (True, True, 7, 3),      # groups of 3 with a ragged tail: one exchange per group
-    (False, False, 5, 2), (True, True, 4, 8),   # unpipelined groups; a group larger than the epoch
+@pytest.mark.parametrize("use_cache,pipeline_on,n_batches,group_size,ref_shaped", [
+    (False, True, 4, 1, False), (True, True, 3, 1, False), (True, False, 2, 1, False), (False, True, 1, 1, False),
+    (True, True, 7, 3, False),      # groups of 3 with a ragged tail: one exchange per group
+    (False, False, 5, 2, False), (True, True, 4, 8, False),   # unpipelined groups; a group larger than the epoch
+    (True, True, 5, 2, True), (False, True, 3, 1, True),      # the reference's 7-field record: no n_id / x fields
 ])
-def test_distributed_prefetcher_two_ranks_gloo(use_cache, pipeline_on, n_batches, group_size):
+def test_distributed_prefetcher_two_ranks_gloo(use_cache, pipeline_on, n_batches, group_size, ref_shaped):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29650 + (7 * n_batches + 31 * group_size + 3 * int(use_cache) + int(pipeline_on)) % 200
-    procs = [ctx.Process(target=_worker, args=(r, port, use_cache, pipeline_on, n_batches, group_size, q))
+    port = 29650 + (7 * n_batches + 31 * group_size + 3 * int(use_cache) + int(pipeline_on) + 97 * int(ref_shaped)) % 200
+    procs = [ctx.Process(target=_worker, args=(r, port, use_cache, pipeline_on, n_batches, group_size, q, ref_shaped))
              for r in range(P)]
     for p in procs:
         p.start()
