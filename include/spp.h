@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPP_ABI_VERSION 2
+#define SPP_ABI_VERSION 3
 #define SPP_MAX_HOPS 8
 #define SPP_MAX_PARTS 64
 
@@ -55,6 +55,18 @@ int spp_device_count(void);
 #define SPP_PROF_KINDS 2
 void spp_profile_enable(int on);
 spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
+
+/* Asynchronously detected data errors.  The reference's CPU code does not range-check row indices
+ * (fast_sampler.cpp:253-256 copies in[idx[i]] blindly); here a kernel that meets an index outside
+ * its table clamps it to a valid row (no fault) and raises a bit in a per-device word in pinned host
+ * memory, so a peer's bucketing bug surfaces as an error instead of wrong features.  The word is
+ * read without any device synchronisation (a bit becomes visible once the offending kernel has run);
+ * spp_session_next reports it as SPP_ERR_STATE, other callers poll it with spp_async_errors. */
+#define SPP_AERR_GATHER_INDEX 1   /* spp_gather_rows*: idx[i] outside [0, src_rows)                       */
+#define SPP_AERR_SERVE_ID 2       /* native exchange: a peer requested a row this rank does not own      */
+#define SPP_AERR_ASSEMBLE 4       /* feature assembly: a source row outside its table                    */
+/* returns the error mask of `device` (>= 0) or a negative spp_status; clear != 0 resets it */
+int spp_async_errors(int device, int clear);
 
 /* ------------------------------------------------------------------------- *
  * a1  std::mt19937 stream (fast_sampler/sample_cpu.hpp:11, seeding
@@ -269,6 +281,14 @@ typedef struct spp_session_cfg {
   const spp_partition_cfg* part;
   /* Optional native feature exchange (NULL = off; needs `part`).  See spp_exchange_cfg below. */
   const struct spp_exchange_cfg* exchange;
+  /* Ordering of the session's own streams against the producer of its device inputs.  idx_dev (and
+   * the feature / label / cache tables handed to export or spp_exchange_cfg) may still be the output
+   * of work QUEUED on the caller's stream (e.g. a shuffle kernel writing this epoch's seed ids): with
+   * order_after_input_stream != 0 every stream the session launches on first waits for what
+   * `input_stream` (a hipStream_t, NULL = the null stream) holds at creation time.  0 = the inputs
+   * are complete already. */
+  void* input_stream;
+  int32_t order_after_input_stream;
 } spp_session_cfg;
 
 typedef struct spp_batch_desc {

@@ -52,7 +52,8 @@ class SessionCfg(C.Structure):
                 ("sizes", i64 * SPP_MAX_HOPS), ("skip_nonfull_batch", i32),
                 ("force_exact_num_batches", i32), ("exact_num_batches", i64),
                 ("max_items_in_queue", i32), ("group_size", i32), ("device", i32), ("sampler", p),
-                ("part", C.POINTER(PartitionCfg)), ("exchange", C.POINTER(ExchangeCfg))]
+                ("part", C.POINTER(PartitionCfg)), ("exchange", C.POINTER(ExchangeCfg)),
+                ("input_stream", p), ("order_after_input_stream", i32)]
 
 
 class BatchDesc(C.Structure):
@@ -65,6 +66,7 @@ SIGNATURES = {
     "spp_abi_version": (C.c_int, []),
     "spp_last_error": (C.c_char_p, []),
     "spp_device_count": (C.c_int, []),
+    "spp_async_errors": (C.c_int, [C.c_int, C.c_int]),
     "spp_profile_enable": (None, [C.c_int]),
     "spp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "spp_mt19937_fill": (C.c_int, [u32, i64, i64, p, p]),
@@ -139,7 +141,7 @@ def load():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.spp_abi_version() != 2:
+        if L.spp_abi_version() != 3:
             raise SppError("libspp_hip.so ABI version mismatch")
         _lib = L
     return _lib

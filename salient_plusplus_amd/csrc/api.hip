@@ -36,6 +36,37 @@ void prof_end(int kind, int idx, hipStream_t st) {
   if (idx < (int)g_prof[kind].size()) (void)hipEventRecord(g_prof[kind][idx].b, st);
 }
 
+// ---- asynchronously detected data errors (spp_async_errors) ----
+static std::mutex g_aerr_mu;
+static int32_t* g_aerr[64] = {};
+
+int32_t* async_err_word(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_aerr_mu);
+  if (!g_aerr[device]) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    int32_t* w = nullptr;
+    // coherent + mapped: one pointer valid on host and device, device writes visible without a flush
+    if (hipHostMalloc((void**)&w, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipSetDevice(prev);
+      return nullptr;
+    }
+    *w = 0;
+    g_aerr[device] = w;
+    (void)hipSetDevice(prev);
+  }
+  return g_aerr[device];
+}
+
+int32_t* async_err_word_current() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) return nullptr;
+  return async_err_word(d);
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -58,6 +89,16 @@ int spp_device_count(void) {
     return -1;
   }
   return n;
+}
+
+int spp_async_errors(int device, int clear) {
+  int32_t* w = spp::async_err_word(device);
+  if (!w) {
+    spp::set_error("spp_async_errors: no error word for device %d", device);
+    return SPP_ERR_HIP;
+  }
+  const int32_t v = clear ? __atomic_exchange_n(w, 0, __ATOMIC_ACQ_REL) : __atomic_load_n(w, __ATOMIC_ACQUIRE);
+  return (int)(v & 0x7fffffff);
 }
 
 void spp_profile_enable(int on) {

@@ -13,6 +13,7 @@
 // (fast_trainer/transferers.py:521, :709, :757).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -35,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -77,6 +79,7 @@ RcclApi* rccl_api() {
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) api.lib = nullptr;
+    else api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(h, "ncclCommAbort"));
   });
   return &api;
 }
@@ -96,9 +99,16 @@ class RcclTransport final : public Transport {
   ~RcclTransport() override {
     if (comm_) (void)rccl_api()->CommDestroy(comm_);
   }
+  void abort() override {
+    // ncclCommAbort frees the communicator: nothing may use comm_ afterwards
+    ncclComm_t c = comm_;
+    comm_ = nullptr;
+    if (c) (void)(rccl_api()->CommAbort ? rccl_api()->CommAbort(c) : rccl_api()->CommDestroy(c));
+  }
   int rank() const override { return rank_; }
   int world() const override { return world_; }
   spp_status all_gather(const void* send, void* recv, size_t bytes, hipStream_t st) override {
+    SPP_REQUIRE(comm_, "exchange communicator was aborted");
     SPP_NCCL_TRY(rccl_api()->AllGather(send, recv, bytes, ncclInt8, comm_, st));
     return SPP_OK;
   }
@@ -107,10 +117,12 @@ class RcclTransport final : public Transport {
     return SPP_OK;
   }
   spp_status send(const void* p, size_t bytes, int peer, hipStream_t st) override {
+    SPP_REQUIRE(comm_, "exchange communicator was aborted");
     SPP_NCCL_TRY(rccl_api()->Send(p, bytes, ncclInt8, peer, comm_, st));
     return SPP_OK;
   }
   spp_status recv(void* p, size_t bytes, int peer, hipStream_t st) override {
+    SPP_REQUIRE(comm_, "exchange communicator was aborted");
     SPP_NCCL_TRY(rccl_api()->Recv(p, bytes, ncclInt8, peer, comm_, st));
     return SPP_OK;
   }
@@ -146,7 +158,8 @@ struct LocalWorld {
   std::vector<hipEvent_t> ready, done;             // per rank
   int alive = 0;
 
-  // reusable barrier; returns false when a rank has left (destroyed its communicator)
+  // reusable barrier; returns false when a rank has left (destroyed / aborted its communicator) or
+  // failed to arrive within the exchange timeout (the world is then broken for everybody)
   bool barrier() {
     std::unique_lock<std::mutex> lk(mu);
     if (broken) return false;
@@ -157,9 +170,15 @@ struct LocalWorld {
       cv.notify_all();
       return true;
     }
-    cv.wait(lk, [&] { return generation != gen || broken; });
+    const auto limit = std::chrono::duration<double>(exchange_timeout_s());
+    if (!cv.wait_for(lk, limit, [&] { return generation != gen || broken; })) {
+      broken = true;
+      timed_out = true;
+      cv.notify_all();
+    }
     return !broken;
   }
+  bool timed_out = false;
 };
 
 class LocalTransport final : public Transport {
@@ -231,8 +250,19 @@ class LocalTransport final : public Transport {
     if (!w_->barrier()) return gone();  // op lists / events are reused by the next collective
     return SPP_OK;
   }
-  static spp_status gone() {
-    set_error("local transport: a peer rank left the communicator");
+  void abort() override {
+    std::lock_guard<std::mutex> lk(w_->mu);
+    w_->broken = true;
+    w_->cv.notify_all();
+  }
+
+ private:
+  spp_status gone() {
+    if (w_->timed_out)
+      set_error("local transport: rank %d waited %.0f s for its peers (a rank is missing, or the ranks disagree on the "
+                "batch sequence)", rank_, exchange_timeout_s());
+    else
+      set_error("local transport: a peer rank left the communicator");
     return SPP_ERR_STATE;
   }
   std::shared_ptr<LocalWorld> w_;

@@ -20,7 +20,13 @@ class Transport {
   virtual spp_status send(const void* p, size_t bytes, int peer, hipStream_t st) = 0;
   virtual spp_status recv(void* p, size_t bytes, int peer, hipStream_t st) = 0;
   virtual spp_status group_end(hipStream_t st) = 0;
+  // Give up on the communicator after a peer failed to arrive: collectives already queued on a
+  // stream must leave the device (ncclCommAbort), later calls fail.  Idempotent.
+  virtual void abort() = 0;
 };
+
+// seconds a rank waits for its peers inside an exchange (SPP_EXCHANGE_TIMEOUT_S, default 300)
+double exchange_timeout_s();
 
 Transport* comm_transport(spp_comm* c);
 

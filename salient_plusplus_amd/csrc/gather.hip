@@ -10,16 +10,18 @@
 namespace spp {
 
 template <int VEC, typename IdxT, bool kNT>
-__global__ __launch_bounds__(kGatherThreads) void k_gather_rows(const char* __restrict__ src,
+__global__ __launch_bounds__(kGatherThreads) void k_gather_rows(const char* __restrict__ src, int64_t src_rows,
                                                                  const IdxT* __restrict__ idx, int64_t n,
                                                                  int64_t row_bytes, int chunks, int lpr_log2,
-                                                                 char* __restrict__ dst, int64_t src_stride) {
-  gather_rows_body<VEC, IdxT, kNT>(src, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x, gridDim.x, src_stride);
+                                                                 char* __restrict__ dst, int64_t src_stride,
+                                                                 int32_t* err) {
+  gather_rows_checked_body<VEC, IdxT, kNT>(src, src_rows, idx, n, row_bytes, chunks, lpr_log2, dst, blockIdx.x,
+                                           gridDim.x, src_stride, err, SPP_AERR_GATHER_INDEX);
 }
 
 template <typename IdxT>
-static spp_status launch_gather(const void* src, int64_t row_bytes, int64_t src_stride, const IdxT* idx, int64_t n,
-                                void* dst, hipStream_t st) {
+static spp_status launch_gather(const void* src, int64_t src_rows, int64_t row_bytes, int64_t src_stride,
+                                const IdxT* idx, int64_t n, void* dst, hipStream_t st) {
   if (n <= 0 || row_bytes <= 0) return SPP_OK;
   if (src_stride <= 0) src_stride = row_bytes;
   const GatherGeom gg = gather_geometry(src, dst, row_bytes, n, src_stride);
@@ -27,16 +29,17 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, int64_t src_
   const int64_t grid = gg.grid;
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
+  int32_t* err = async_err_word_current();
   const int prof = prof_begin(SPP_PROF_GATHER, st, n);
   static const bool nt = [] { const char* e = getenv("SPP_GATHER_NT"); return e ? atoi(e) != 0 : false; }();
 #define SPP_LAUNCH_GATHER(V)                                                                                    \
   do {                                                                                                          \
     if (nt)                                                                                                     \
       hipLaunchKernelGGL((k_gather_rows<V, IdxT, true>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s,  \
-                         idx, n, row_bytes, chunks, lpr_log2, d, src_stride);                                   \
+                         src_rows, idx, n, row_bytes, chunks, lpr_log2, d, src_stride, err);                    \
     else                                                                                                        \
       hipLaunchKernelGGL((k_gather_rows<V, IdxT, false>), dim3((unsigned)grid), dim3(kGatherThreads), 0, st, s, \
-                         idx, n, row_bytes, chunks, lpr_log2, d, src_stride);                                   \
+                         src_rows, idx, n, row_bytes, chunks, lpr_log2, d, src_stride, err);                    \
   } while (0)
   switch (gg.vec) {
     case 16: SPP_LAUNCH_GATHER(16); break;
@@ -52,9 +55,9 @@ static spp_status launch_gather(const void* src, int64_t row_bytes, int64_t src_
 }
 
 // used by sampler.hip (int32 node list of a slot)
-spp_status gather_rows_i32(const void* src, int64_t row_bytes, int64_t src_stride, const int32_t* idx, int64_t n,
-                           void* dst, hipStream_t st) {
-  return launch_gather<int32_t>(src, row_bytes, src_stride, idx, n, dst, st);
+spp_status gather_rows_i32(const void* src, int64_t src_rows, int64_t row_bytes, int64_t src_stride,
+                           const int32_t* idx, int64_t n, void* dst, hipStream_t st) {
+  return launch_gather<int32_t>(src, src_rows, row_bytes, src_stride, idx, n, dst, st);
 }
 
 // ---- to_row_major (reference fast_sampler.cpp:281-308): out[r*tc + c] = in[c*tr + r] ----
@@ -96,12 +99,13 @@ extern "C" spp_status spp_gather_rows_strided(const void* src_dev, int64_t src_r
   const int64_t n = n_idx < n_out ? n_idx : n_out;  // reference :253  min(idx.numel(), n)
   if (n == 0 || row_bytes == 0) return SPP_OK;
   SPP_REQUIRE(src_dev && idx_dev && dst_dev, "spp_gather_rows: NULL buffer");
-  (void)src_rows;
+  SPP_REQUIRE(src_rows > 0, "spp_gather_rows: %lld rows requested from an empty table (src_rows %lld)", (long long)n,
+              (long long)src_rows);
   if (idx_elem_bytes == 8)
-    return spp::launch_gather<int64_t>(src_dev, row_bytes, src_stride_bytes, static_cast<const int64_t*>(idx_dev), n,
-                                       dst_dev, spp::as_stream(stream));
-  return spp::launch_gather<int32_t>(src_dev, row_bytes, src_stride_bytes, static_cast<const int32_t*>(idx_dev), n,
-                                     dst_dev, spp::as_stream(stream));
+    return spp::launch_gather<int64_t>(src_dev, src_rows, row_bytes, src_stride_bytes,
+                                       static_cast<const int64_t*>(idx_dev), n, dst_dev, spp::as_stream(stream));
+  return spp::launch_gather<int32_t>(src_dev, src_rows, row_bytes, src_stride_bytes,
+                                     static_cast<const int32_t*>(idx_dev), n, dst_dev, spp::as_stream(stream));
 }
 
 extern "C" spp_status spp_to_row_major(const void* src_dev, int64_t rows, int64_t cols, int elem_bytes, void* dst_dev,

@@ -101,4 +101,25 @@ __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, c
                            lpr_log2, dst, vblock, nvblocks);
 }
 
+// Same with caller-supplied (untrusted) indices: an index outside [0, src_rows) reads row 0 and raises
+// SPP_AERR_GATHER_INDEX in `err` (the reference's serial_index would read out of bounds).
+template <int VEC, typename IdxT, bool kNT = false>
+__device__ __forceinline__ void gather_rows_checked_body(const char* __restrict__ src, int64_t src_rows,
+                                                         const IdxT* __restrict__ idx, int64_t n, int64_t row_bytes,
+                                                         int chunks, int lpr_log2, char* __restrict__ dst,
+                                                         int64_t vblock, int64_t nvblocks, int64_t src_stride,
+                                                         int32_t* err, int32_t err_bit) {
+  if (n <= 0) return;
+  move_rows_body<VEC, kNT>(
+      [=](int64_t r) {
+        int64_t i = (int64_t)idx[r];
+        if ((uint64_t)i >= (uint64_t)src_rows) {
+          if (err) __hip_atomic_fetch_or(err, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          i = 0;
+        }
+        return src + i * src_stride;
+      },
+      n, row_bytes, chunks, lpr_log2, dst, vblock, nvblocks);
+}
+
 }  // namespace spp

@@ -178,6 +178,8 @@ struct AsmArgs {
   int64_t row_bytes;
   int64_t x_local_stride, cache_stride;
   char* out;
+  int64_t x_local_rows;
+  int32_t* err;   // async error word (SPP_AERR_ASSEMBLE)
 };
 
 template <int VEC>
@@ -196,7 +198,14 @@ __global__ __launch_bounds__(kPT) void k_assemble(AsmArgs a, int chunks, int lpr
     int m = 0;
     while (m < a.P && j >= a.seg_start[m + 1]) ++m;
     const char* src;
-    if (m == a.rank) src = a.x_local + (a.n_id[r] - a.rank_offset) * a.x_local_stride;
+    if (m == a.rank) {
+      int64_t lr = a.n_id[r] - a.rank_offset;
+      if ((uint64_t)lr >= (uint64_t)a.x_local_rows) {  // perm / n_id / partition book disagree
+        raise_async_error(a.err, SPP_AERR_ASSEMBLE);
+        lr = 0;
+      }
+      src = a.x_local + lr * a.x_local_stride;
+    }
     else if (m == a.P) src = a.cache_feats + a.cached_nids[j - a.seg_start[a.P]] * a.cache_stride;
     else src = a.recv + (a.recv_base[m] + (j - a.seg_start[m])) * a.row_bytes;
     const V* s = reinterpret_cast<const V*>(src);
@@ -333,7 +342,10 @@ extern "C" spp_status spp_assemble_features(const int64_t* n_id_dev, const int64
   SPP_REQUIRE(recv_dev || rb == 0, "spp_assemble_features: recv is NULL");
   SPP_REQUIRE((cache_feats_dev && cached_nids_dev) || seg_start_host[P + 1] == seg_start_host[P],
               "spp_assemble_features: cache rows requested without a cache");
-  (void)x_local_rows;
+  SPP_REQUIRE(x_local_rows > 0 || seg_start_host[rank + 1] == seg_start_host[rank],
+              "spp_assemble_features: local rows requested from an empty x_local");
+  a.x_local_rows = x_local_rows;
+  a.err = async_err_word_current();
   a.rank_offset = rank_offset;
   a.x_local = static_cast<const char*>(x_local_dev);
   a.recv = static_cast<const char*>(recv_dev);

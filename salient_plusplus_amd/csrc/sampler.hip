@@ -60,8 +60,8 @@
 
 namespace spp {
 
-spp_status gather_rows_i32(const void* src, int64_t row_bytes, int64_t src_stride, const int32_t* idx, int64_t n,
-                           void* dst, hipStream_t st);
+spp_status gather_rows_i32(const void* src, int64_t src_rows, int64_t row_bytes, int64_t src_stride,
+                           const int32_t* idx, int64_t n, void* dst, hipStream_t st);
 
 constexpr int kNT = 256;         // workgroup size of the per-target / per-edge kernels
 constexpr int kFastMaxFanout = 32;
@@ -92,6 +92,7 @@ struct SlotState {
   int64_t dbase[SPP_MAX_HOPS + 1]; // RNG draws consumed before hop h (relative to rng_skip)
   int32_t error;
   int32_t pad;
+  const uint32_t* rng;             // this batch's mt19937 draws (slot buffer or the sampler's epoch arena)
   int32_t pcnt[kPartBuckets];      // ownership buckets of the node list (spp_partition_cfg): [0,P) owners, [P] cache hits
 };
 
@@ -127,11 +128,12 @@ struct SlotPtrs {
 struct GroupArgs {
   int32_t first_slot;
   int32_t n;
-  int32_t rng_buf;
+  int32_t rng_buf;                 // slot ping-pong buffer holding the draws (ignored when rng[i] is set)
   const int64_t* seeds[kMaxGroup];
   int32_t n_seeds[kMaxGroup];
   uint32_t rng_seed[kMaxGroup];
   int64_t rng_skip[kMaxGroup];
+  const uint32_t* rng[kMaxGroup];  // draws of batch i in the epoch arena (NULL: the slot's rng[rng_buf])
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -202,6 +204,19 @@ __global__ __launch_bounds__(kMtThreads) void k_rng_fill(const SlotPtrs* __restr
   mt_block_advance(x, 624, skip + dcap, skip, cap, out);
 }
 
+// The streams of a whole epoch in one launch: stream b = draws [0, dcap) of mt19937(seeds[b]) at
+// arena + b * stride.  A batch's generator seed is a function of its range end only
+// (fast_sampler.cpp:994) and the range table repeats every epoch, so this runs once per range table
+// and the result is kept by the sampler: 1178 batches x 4.3 MB = 5 GB at papers100M scale (288 GB HBM).
+__global__ __launch_bounds__(kMtThreads) void k_rng_arena(uint32_t* __restrict__ arena, int64_t stride,
+                                                           const uint32_t* __restrict__ seeds, int64_t dcap) {
+  __shared__ uint32_t x[2 * kMtRing];
+  uint32_t* out = arena + (int64_t)blockIdx.x * stride;
+  const int64_t cap = dcap + kMtSlack;
+  mt_block_seed(x, seeds[blockIdx.x], 0, cap, out);
+  mt_block_advance(x, 624, dcap, 0, cap, out);
+}
+
 // One-off int32 copy of the neighbour array (node ids are < 2^31, fast_sampler.cpp:196-199 narrows them
 // anyway): a sampled row spans half as many 128-B fetch granules, and the random neighbour reads of the
 // last hop are the sampler's largest single source of HBM traffic.
@@ -223,6 +238,7 @@ __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ 
     s.st->cnt[0] = n_seeds;
     s.st->dbase[0] = 0;
     s.st->error = 0;
+    s.st->rng = ga.rng[blockIdx.y] ? ga.rng[blockIdx.y] : s.rng[ga.rng_buf];
   }
   if (i < n_seeds) {
     const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
@@ -333,8 +349,8 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 template <bool kGeneric, typename ColT>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, int32_t first_slot,
-                                                   int32_t rng_buf, const ColT* __restrict__ col, int32_t h,
-                                                   int32_t f, int32_t replace) {
+                                                   const ColT* __restrict__ col, int32_t h, int32_t f,
+                                                   int32_t replace) {
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, then neighbour ids; column per lane
   const SlotPtrs& s = slots[first_slot + blockIdx.y];
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   if (i >= T) return;
   s.out_rowptr[h][i] = p0;
   if (s.st->error) return;
-  const uint32_t* rng = s.rng[rng_buf];
+  const uint32_t* rng = s.st->rng;
   if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
   if (kGeneric) {
     // only the Floyd picks are produced here (into evals[p0..p0+f), free at this point; erank still
@@ -979,6 +995,14 @@ struct spp_sampler {
   int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
   std::shared_ptr<Col32> col32_owner;  // int32 copy of cfg.col_dev, shared by the samplers of one graph
   int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
+  // epoch arena of mt19937 streams (sampler_rng_arena): one stream per batch of the current range table
+  uint32_t* rng_arena = nullptr;
+  int64_t rng_arena_words = 0;       // allocated size
+  int64_t rng_arena_stride = 0;      // words between consecutive batches' streams
+  std::vector<uint32_t> rng_arena_seeds;  // seeds the arena currently holds (empty: nothing generated)
+  uint32_t* rng_arena_seeds_dev = nullptr;
+  int64_t rng_arena_seeds_cap = 0;
+  hipEvent_t rng_arena_ready = nullptr;
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
   XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
 };
@@ -1221,6 +1245,9 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.p.erank) (void)hipFree(sl.p.erank);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
+  if (s->rng_arena) (void)hipFree(s->rng_arena);
+  if (s->rng_arena_seeds_dev) (void)hipFree(s->rng_arena_seeds_dev);
+  if (s->rng_arena_ready) (void)hipEventDestroy(s->rng_arena_ready);
   if (s->h_states) (void)hipHostFree(s->h_states);
   if (s->deliver_stream) (void)hipStreamDestroy(s->deliver_stream);
   for (auto st : s->work_streams)
@@ -1312,9 +1339,69 @@ spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, co
   return SPP_OK;
 }
 
+// Epoch arena: the mt19937 streams of ALL batches of an epoch (seeds[b] = spp_batch_seed(range b's end)),
+// generated by one launch on `st` the first time this seed table is seen and kept until a session
+// brings a different one.  Returns false (and leaves *base NULL) when the arena would exceed
+// SPP_RNG_ARENA_MB (default 16384) or cannot be allocated: the caller then generates per group into
+// the slots' ping-pong buffers as before.  *ready: event to order other streams after the generation.
+spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, hipStream_t st, const uint32_t** base,
+                             int64_t* stride, hipEvent_t* ready) {
+  *base = nullptr;
+  *stride = 0;
+  *ready = nullptr;
+  if (s->dcap <= 0 || nb <= 0) return SPP_OK;
+  static const int64_t budget_words = [] {
+    const char* e = getenv("SPP_RNG_ARENA_MB");
+    const int64_t mb = e ? atoll(e) : 16384;
+    return (mb < 0 ? 0 : mb) * (int64_t)(1 << 20) / 4;
+  }();
+  const int64_t stride_w = (s->dcap + kMtSlack + 31) / 32 * 32;  // 128-B aligned streams
+  const int64_t need = stride_w * nb;
+  if (need > budget_words) return SPP_OK;
+  const bool same = (int64_t)s->rng_arena_seeds.size() == nb && s->rng_arena_stride == stride_w &&
+                    std::equal(seeds, seeds + nb, s->rng_arena_seeds.begin());
+  if (!same) {
+    s->rng_arena_seeds.clear();
+    if (need > s->rng_arena_words) {
+      if (s->rng_arena) {
+        (void)hipFree(s->rng_arena);
+        s->bytes -= 4 * s->rng_arena_words;
+      }
+      s->rng_arena = nullptr;
+      s->rng_arena_words = 0;
+      if (hipMalloc((void**)&s->rng_arena, sizeof(uint32_t) * (size_t)need) != hipSuccess) {
+        (void)hipGetLastError();  // not fatal: fall back to per-group generation
+        s->rng_arena = nullptr;
+        return SPP_OK;
+      }
+      s->rng_arena_words = need;
+      s->bytes += 4 * need;
+    }
+    if (nb > s->rng_arena_seeds_cap) {
+      if (s->rng_arena_seeds_dev) (void)hipFree(s->rng_arena_seeds_dev);
+      s->rng_arena_seeds_dev = nullptr;
+      SPP_HIP_TRY(hipMalloc((void**)&s->rng_arena_seeds_dev, sizeof(uint32_t) * (size_t)nb));
+      s->rng_arena_seeds_cap = nb;
+    }
+    if (!s->rng_arena_ready) SPP_HIP_TRY(hipEventCreateWithFlags(&s->rng_arena_ready, hipEventDisableTiming));
+    SPP_HIP_TRY(hipMemcpyAsync(s->rng_arena_seeds_dev, seeds, sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice, st));
+    SPP_HIP_TRY(hipStreamSynchronize(st));  // `seeds` is the caller's pageable memory
+    hipLaunchKernelGGL(k_rng_arena, dim3((unsigned)nb), dim3(kMtThreads), 0, st, s->rng_arena, stride_w,
+                       s->rng_arena_seeds_dev, s->dcap);
+    SPP_HIP_TRY(hipGetLastError());
+    SPP_HIP_TRY(hipEventRecord(s->rng_arena_ready, st));
+    s->rng_arena_stride = stride_w;
+    s->rng_arena_seeds.assign(seeds, seeds + nb);
+  }
+  *base = s->rng_arena;
+  *stride = stride_w;
+  *ready = s->rng_arena_ready;
+  return SPP_OK;
+}
+
 // sampling chain of a group of batches (RNG already in rng[buf]); records the group's completion event
 spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
-                                const int64_t* n_seeds, hipStream_t st) {
+                                const int64_t* n_seeds, hipStream_t st, const uint32_t* const* rng_streams) {
   SPP_REQUIRE(n >= 1 && n <= sampler_max_group(s), "sampler_launch_chain: group of %d batches not supported", n);
   SPP_REQUIRE(first_slot >= 0 && first_slot + n <= (int)s->slots.size(), "sampler_launch_chain: slots out of range");
   const int H = s->cfg.num_hops;
@@ -1333,6 +1420,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     SPP_REQUIRE(seeds_dev[i] || n_seeds[i] == 0, "spp_sampler: seeds_dev is NULL");
     ga.seeds[i] = seeds_dev[i];
     ga.n_seeds[i] = (int32_t)n_seeds[i];
+    ga.rng[i] = rng_streams ? rng_streams[i] : nullptr;
     max_seeds = std::max(max_seeds, n_seeds[i]);
   }
   const unsigned gy = (unsigned)n;
@@ -1354,11 +1442,11 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     unsigned ge;
     if (!s->generic[h]) {
       if (col32)
-        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf,
-                           col32, h, f, replace);
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col32,
+                           h, f, replace);
       else
-        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf,
-                           col, h, f, replace);
+        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h,
+                           f, replace);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -1368,8 +1456,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       if (lead.host_state->error) break;
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, buf, col,
-                         h, f, replace);
+      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h, f,
+                         replace);
       if (col32)
         hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col32,
                            h, f, replace);
@@ -1592,7 +1680,7 @@ extern "C" spp_status spp_sampler_sample(spp_sampler* s, int32_t slot, const int
   SPP_REQUIRE(rng_skip >= 0, "spp_sampler_sample: rng_skip must be >= 0");
   hipStream_t st = as_stream(stream);
   SPP_TRY(sampler_launch_rng(s, slot, 1, 0, &rng_seed, &rng_skip, st));
-  return sampler_launch_chain(s, slot, 1, 0, &seeds_dev, &n_seeds, st);
+  return sampler_launch_chain(s, slot, 1, 0, &seeds_dev, &n_seeds, st, nullptr);
 }
 
 static void fill_counts(const spp_sampler* s, const SlotState* hs, spp_mfg_counts* out) {
@@ -1686,7 +1774,7 @@ extern "C" spp_status spp_sampler_gather(spp_sampler* s, int32_t slot, const voi
   const int64_t n = (n_rows < 0 || n_rows > U) ? U : n_rows;
   if (n == 0 || row_bytes == 0) return SPP_OK;
   SPP_REQUIRE(src_dev && dst_dev, "spp_sampler_gather: NULL buffer");
-  (void)src_rows;
   SPP_REQUIRE(src_stride_bytes == 0 || src_stride_bytes >= row_bytes, "spp_sampler_gather: bad source stride");
-  return gather_rows_i32(src_dev, row_bytes, src_stride_bytes, sl.p.n_ids, n, dst_dev, as_stream(stream));
+  SPP_REQUIRE(src_rows > 0, "spp_sampler_gather: empty source table");
+  return gather_rows_i32(src_dev, src_rows, row_bytes, src_stride_bytes, sl.p.n_ids, n, dst_dev, as_stream(stream));
 }

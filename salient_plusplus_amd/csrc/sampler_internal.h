@@ -21,8 +21,14 @@ spp_status sampler_launch_rng(spp_sampler* s, int first_slot, int n, int buf, co
 
 // Enqueue the sampling chain of `n` batches whose RNG streams are in buffer `buf`; records the
 // group's completion event (spp_sampler_wait on any slot of the group waits for it).
+// rng_streams: NULL, or per batch the device pointer of its draws in the epoch arena (then `buf` is unused).
 spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, const int64_t* const* seeds_dev,
-                                const int64_t* n_seeds, hipStream_t st);
+                                const int64_t* n_seeds, hipStream_t st, const uint32_t* const* rng_streams);
+
+// The mt19937 streams of a whole epoch, kept by the sampler across Sessions (see sampler.hip).
+// *base == NULL on return: no arena (over budget / allocation failed) -> generate per group.
+spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, hipStream_t st, const uint32_t** base,
+                             int64_t* stride, hipEvent_t* ready);
 
 // Where the feature rows of a distributed batch come from (native exchange, session.hip): row r of
 // x is row pperm[r] of the virtual concatenation [owner 0 | ... | owner P-1 | cache hits]; the

@@ -52,11 +52,16 @@ __global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __res
                                                                const int32_t* __restrict__ ids, int64_t n,
                                                                int64_t rank_offset, int64_t row_bytes,
                                                                int64_t src_stride, int chunks, int lpr_log2,
-                                                               char* __restrict__ out) {
+                                                               char* __restrict__ out, int32_t* err) {
   move_rows_body<VEC, false>(
       [=](int64_t j) -> const char* {
         int64_t r = (int64_t)ids[j] - rank_offset;
-        r = r < 0 ? 0 : (r >= x_rows ? x_rows - 1 : r);  // a peer only asks for rows this rank owns
+        if ((uint64_t)r >= (uint64_t)x_rows) {
+          // a peer only asks for rows this rank owns: anything else is a bucketing / partition-book
+          // mismatch between the ranks -- serve row 0 (no fault) and report it (SPP_AERR_SERVE_ID)
+          raise_async_error(err, SPP_AERR_SERVE_ID);
+          r = 0;
+        }
         return x_local + r * src_stride;
       },
       n, row_bytes, chunks, lpr_log2, out, blockIdx.x, gridDim.x);
@@ -114,7 +119,42 @@ struct spp_session {
   std::string exchange_err;
   std::vector<XSet> xsets;
   std::atomic<int64_t> sent_bytes{0}, recv_bytes{0};
+  bool comm_failed = false;              // an exchange timed out / a peer left: comm_stream may never drain
+  // epoch arena of mt19937 streams (sampler_rng_arena); NULL: per-group generation into the slots
+  const uint32_t* rng_base = nullptr;
+  int64_t rng_stride = 0;
 };
+
+// how long a rank waits for its peers inside an exchange before giving up with a message
+// (SPP_EXCHANGE_TIMEOUT_S, default 300 s); read on every use so a caller may change it
+namespace spp {
+double exchange_timeout_s() {
+  const char* e = getenv("SPP_EXCHANGE_TIMEOUT_S");
+  const double v = e ? atof(e) : 300.0;
+  return v > 0 ? v : 300.0;
+}
+}  // namespace spp
+
+// Bounded wait for an event that completes only when every peer has taken part in a collective.
+static spp_status wait_peers(spp_session* s, hipEvent_t ev, const char* what, long long g) {
+  const double limit_s = exchange_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return SPP_OK;
+    if (q != hipErrorNotReady) SPP_HIP_TRY(q);
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+      // The collective stays queued on comm_stream: abort the communicator so that its kernels leave
+      // the device, and remember that the stream may never drain (teardown must not wait for it).
+      s->comm_failed = true;
+      if (s->tr) s->tr->abort();
+      set_error("%s (group %lld): rank %d waited %.0f s for its peers (a rank is missing, or the ranks disagree on "
+                "the batch sequence); the exchange communicator was aborted", what, g, s->rank, limit_s);
+      return SPP_ERR_STATE;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
 
 // fast_sampler.cpp:587-627
 static void build_ranges(const spp_session_cfg& c, std::vector<std::pair<int32_t, int32_t>>& out) {
@@ -181,7 +221,9 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
     seeds[i] = s->cfg.idx_dev + r.first;
     n_seeds[i] = (int64_t)r.second - r.first;
   }
-  if (g < s->num_sets) SPP_TRY(launch_group_rng(s, g));
+  const uint32_t* rng_streams[kMaxGroup];
+  for (int i = 0; i < n; ++i) rng_streams[i] = s->rng_base ? s->rng_base + (g * s->G + i) * s->rng_stride : nullptr;
+  if (!s->rng_base && g < s->num_sets) SPP_TRY(launch_group_rng(s, g));
   // the consumer's copies out of these slots (previous group of this slot-set) must be done
   for (int i = 0; i < s->G; ++i) {
     const size_t slot = (size_t)(set * s->G + i);
@@ -192,8 +234,8 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
   }
   // ... and the previous exchange out of these slots (its sends read the slots' id lists)
   if (s->tr && s->xsets[(size_t)set].rows_recorded) SPP_HIP_TRY(hipStreamWaitEvent(st, s->xsets[(size_t)set].rows_done, 0));
-  SPP_TRY(sampler_launch_chain(s->sampler, set * s->G, n, buf, seeds, n_seeds, st));
-  if (g + s->num_sets < s->num_groups) SPP_TRY(launch_group_rng(s, g + s->num_sets));
+  SPP_TRY(sampler_launch_chain(s->sampler, set * s->G, n, buf, seeds, n_seeds, st, s->rng_base ? rng_streams : nullptr));
+  if (!s->rng_base && g + s->num_sets < s->num_groups) SPP_TRY(launch_group_rng(s, g + s->num_sets));
   return SPP_OK;
 }
 
@@ -242,11 +284,13 @@ static spp_status wait_group_launched(spp_session* s, int64_t g) {
 // ---- native exchange -----------------------------------------------------------------------------
 static spp_status launch_serve(spp_session* s, const int32_t* ids, int64_t n, char* out, hipStream_t st) {
   if (n <= 0) return SPP_OK;
+  SPP_REQUIRE(s->xcfg.x_local_rows > 0, "exchange: peers request %lld rows but this rank owns none", (long long)n);
+  int32_t* err = async_err_word(s->cfg.device);
   const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n, s->xcfg.x_local_stride_bytes);
   const char* x = static_cast<const char*>(s->xcfg.x_local_dev);
 #define SPP_SERVE(V)                                                                                              \
   hipLaunchKernelGGL(k_serve_rows<V>, dim3((unsigned)gg.grid), dim3(kGatherThreads), 0, st, x, s->xcfg.x_local_rows, \
-                     ids, n, s->rank_offset, s->xcfg.row_bytes, s->xcfg.x_local_stride_bytes, gg.chunks, gg.lpr_log2, out)
+                     ids, n, s->rank_offset, s->xcfg.row_bytes, s->xcfg.x_local_stride_bytes, gg.chunks, gg.lpr_log2, out, err)
   switch (gg.vec) {
     case 16: SPP_SERVE(16); break;
     case 8: SPP_SERVE(8); break;
@@ -317,28 +361,10 @@ static spp_status exchange_group(spp_session* s, int64_t g) {
   SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.send_ids, &xb.send_ids_cap, total_in, 4));
   SPP_TRY(sampler_xbuf_grow(s->sampler, (void**)&xb.recv_rows, &xb.recv_rows_cap, total_in, rb));
   if (total_in > 0) SPP_TRY(sampler_pack_remote_ids(s->sampler, set * G, n, x.cnt_dev + ge, xb.send_ids, st));
-  {
-    // wait for the gathered counts -- i.e. for every peer to reach this group.  A peer that never
-    // arrives (crashed rank, unequal batch counts slipping past the creation-time check) would make
-    // this wait forever: give up with a message after SPP_EXCHANGE_TIMEOUT_S seconds (default 300).
-    static const double limit_s = [] {
-      const char* e = getenv("SPP_EXCHANGE_TIMEOUT_S");
-      const double v = e ? atof(e) : 300.0;
-      return v > 0 ? v : 300.0;
-    }();
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      const hipError_t q = hipEventQuery(x.cnt_ready);
-      if (q == hipSuccess) break;
-      if (q != hipErrorNotReady) SPP_HIP_TRY(q);
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
-        set_error("exchange of group %lld: rank %d waited %.0f s for its peers' request counts (a rank is missing, or "
-                  "the ranks disagree on the batch sequence)", (long long)g, R, limit_s);
-        return SPP_ERR_STATE;
-      }
-      std::this_thread::sleep_for(std::chrono::microseconds(20));
-    }
-  }
+  // wait for the gathered counts -- i.e. for every peer to reach this group.  A peer that never arrives
+  // (crashed rank, unequal batch counts slipping past the creation-time check) would make this wait
+  // forever: give up with a message after SPP_EXCHANGE_TIMEOUT_S seconds.
+  SPP_TRY(wait_peers(s, x.cnt_ready, "exchange of request counts", (long long)g));
   // rows peer m wants from this rank (all batches of the group, in batch order)
   int64_t serve_for[SPP_MAX_PARTS], out_base[SPP_MAX_PARTS];
   int64_t total_req = 0;
@@ -456,7 +482,11 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
     SPP_HIP_TRY(hipMemcpyAsync(x0.cnt_dev, x0.cnt_host, 16, hipMemcpyHostToDevice, s->comm_stream));
     SPP_TRY(tr->all_gather(x0.cnt_dev, x0.cnt_dev + 2, 16, s->comm_stream));
     SPP_HIP_TRY(hipMemcpyAsync(x0.cnt_host + 2, x0.cnt_dev + 2, 16 * (size_t)s->P, hipMemcpyDeviceToHost, s->comm_stream));
-    SPP_HIP_TRY(hipStreamSynchronize(s->comm_stream));
+    SPP_HIP_TRY(hipEventRecord(x0.cnt_ready, s->comm_stream));
+    s->tr = tr;  // wait_peers aborts it on a timeout
+    const spp_status wrc = wait_peers(s, x0.cnt_ready, "session creation (batch-count check)", -1);
+    s->tr = nullptr;
+    SPP_TRY(wrc);
     for (int m = 0; m < s->P; ++m)
       SPP_REQUIRE(x0.cnt_host[2 + 2 * m] == x0.cnt_host[0] && x0.cnt_host[3 + 2 * m] == x0.cnt_host[1],
                   "spp_session_create: rank %d runs %lld batches in groups of %lld, rank %d runs %lld in groups of %lld "
@@ -469,6 +499,25 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
 }
 
 static void exchange_teardown(spp_session* s) {
+  if (s->comm_failed) {
+    // The communicator was aborted after a timeout.  Give its queued work a moment to leave the
+    // stream; if it does not, LEAK the stream, its events and buffers (hipFree / hipStreamDestroy would
+    // wait for it forever) -- the caller is about to report the error and exit.
+    bool drained = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->comm_stream && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 5.0) {
+      if (hipStreamQuery(s->comm_stream) != hipErrorNotReady) {
+        drained = true;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    if (!drained) {
+      s->comm_stream = nullptr;
+      s->xsets.clear();
+      return;
+    }
+  }
   if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
   for (auto& x : s->xsets) {
     if (x.cnt_dev) (void)hipFree(x.cnt_dev);
@@ -567,6 +616,39 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   s->export_recorded.assign((size_t)(sets * G), 0);
   for (auto& e : s->export_done) mk_event(&e);
   if (rc == SPP_OK && cfg->exchange) rc = exchange_setup(s, cfg->exchange, want);
+  // Order every stream the session launches on after the producer of its device inputs (seed ids
+  // written by a shuffle kernel still queued on the caller's stream, a cache map just built, ...).
+  hipEvent_t inputs_ready = nullptr;
+  if (rc == SPP_OK && cfg->order_after_input_stream) {
+    mk_event(&inputs_ready);
+    if (rc == SPP_OK && hipEventRecord(inputs_ready, as_stream(cfg->input_stream)) != hipSuccess) {
+      set_error("spp_session_create: recording the input event failed");
+      rc = SPP_ERR_HIP;
+    }
+    auto after_inputs = [&](hipStream_t st) {
+      if (rc == SPP_OK && hipStreamWaitEvent(st, inputs_ready, 0) != hipSuccess) {
+        set_error("spp_session_create: hipStreamWaitEvent failed");
+        rc = SPP_ERR_HIP;
+      }
+    };
+    for (auto st : s->streams) after_inputs(st);
+    after_inputs(as_stream(spp_sampler_deliver_stream(s->sampler)));
+    if (s->comm_stream) after_inputs(s->comm_stream);
+  }
+  if (inputs_ready) (void)hipEventDestroy(inputs_ready);  // the waits already enqueued keep their reference
+  // mt19937 streams of the whole epoch: generated once per range table, kept by the (pooled) sampler
+  if (rc == SPP_OK && nb > 0) {
+    std::vector<uint32_t> seeds((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) seeds[(size_t)b] = spp_batch_seed(s->ranges[(size_t)b].second);  // :994
+    hipEvent_t arena_ready = nullptr;
+    rc = sampler_rng_arena(s->sampler, seeds.data(), nb, s->streams[0], &s->rng_base, &s->rng_stride, &arena_ready);
+    if (rc == SPP_OK && s->rng_base && arena_ready)
+      for (size_t i = 1; i < s->streams.size() && rc == SPP_OK; ++i)
+        if (hipStreamWaitEvent(s->streams[i], arena_ready, 0) != hipSuccess) {
+          set_error("spp_session_create: hipStreamWaitEvent failed");
+          rc = SPP_ERR_HIP;
+        }
+  }
   if (rc == SPP_OK) {
     s->launcher = std::thread(launcher_main, s);  // primes the pipeline right away
     if (s->tr && !s->issue_on_consumer) s->exchanger = std::thread(exchanger_main, s);
@@ -592,7 +674,14 @@ extern "C" void spp_session_destroy(spp_session* s) {
   }
   if (s->exchanger.joinable()) s->exchanger.join();  // `stop` is set; it leaves after the group in hand
   (void)hipSetDevice(s->cfg.device);
+  const bool had_comm_stream = s->comm_stream != nullptr;
   exchange_teardown(s);
+  if (s->comm_failed && had_comm_stream && !s->comm_stream) {
+    // the aborted exchange never drained: the sampling streams wait on its events, so nothing here
+    // can be synchronised or freed without hanging -- leak the device side, the caller is failing
+    delete s;
+    return;
+  }
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
   // the consumer's last deliveries still read the slots and the exchange buffers: a (pooled) sampler
@@ -671,13 +760,25 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   const auto t0 = std::chrono::steady_clock::now();
   spp_status rc = wait_group_launched(s, g);
   if (rc == SPP_OK && s->tr && s->issue_on_consumer)
-    rc = issue_exchanges_up_to(s, (b % s->G) * 2 >= s->G ? g + 1 : g);  // own group now, the next one from mid-group
+    // own group now; the next one from mid-group on -- but only when a second slot-set exists: with one
+    // set the launcher cannot start group g+1 before this consumer has finished group g
+    rc = issue_exchanges_up_to(s, (s->num_sets >= 2 && (b % s->G) * 2 >= s->G) ? g + 1 : g);
   if (rc == SPP_OK) rc = spp_sampler_wait(s->sampler, slot, &out->counts);
   if (rc == SPP_OK && s->tr) rc = wait_group_exchanged(s, g);
   const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   if (us > 50) {  // the reference counts only waits that actually spun (fast_sampler.cpp:788-799)
     s->blocked_us += us;
     s->blocked_occasions++;
+  }
+  if (rc == SPP_OK && s->tr) {
+    const int32_t* aw = async_err_word(s->cfg.device);
+    const int32_t bits = aw ? __atomic_load_n(aw, __ATOMIC_ACQUIRE) : 0;
+    if (bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE)) {
+      set_error("feature exchange: a row outside its table was requested (async error mask %d: 2 = a peer asked this "
+                "rank for a row it does not own, 4 = assembly source out of range) -- the ranks disagree on the "
+                "partition book or the bucketing", bits);
+      rc = SPP_ERR_STATE;
+    }
   }
   if (rc != SPP_OK) return rc;
   out->batch_index = b;

@@ -42,6 +42,12 @@ void set_error(const char* fmt, ...);
 int prof_begin(int kind, hipStream_t st, int64_t units);
 void prof_end(int kind, int idx, hipStream_t st);
 
+// Per-device error word in pinned, device-visible host memory (spp_async_errors, include/spp.h):
+// kernels raise SPP_AERR_* bits with a system-scope atomic, the host reads it without synchronising.
+// Returns nullptr when it cannot be allocated (kernels then only clamp).
+int32_t* async_err_word(int device);
+int32_t* async_err_word_current();
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -50,6 +56,10 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 // ---------------------------------------------------------------------------
 // device-side primitives
 // ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void raise_async_error(int32_t* word, int32_t bit) {
+  if (word) __hip_atomic_fetch_or(word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // inclusive scan across one 64-lane wavefront
 template <typename T>

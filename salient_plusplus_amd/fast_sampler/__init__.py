@@ -494,6 +494,11 @@ class Session:
         cfg.max_items_in_queue = slots
         cfg.group_size = int(os.environ.get("SPP_GROUP_SIZE", "0"))   # 0 = auto
         cfg.device = self._dev.index
+        # idx / x / y / the cache map may still be outputs of work queued on the caller's stream (a
+        # shuffle kernel writing this epoch's seeds, Cache.device_map()): the session's own streams
+        # are ordered after what that stream holds now
+        cfg.input_stream = torch.cuda.current_stream(self._dev).cuda_stream
+        cfg.order_after_input_stream = 1
         cfg.sampler = self._pool_entry[0]
         if self._part is not None:
             cfg.part = C.pointer(self._part[0])

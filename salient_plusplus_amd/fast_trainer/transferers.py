@@ -78,6 +78,14 @@ class _HipFeatureOps:
                                                       self._p(out), self._stream()))
         return out
 
+    def check_async(self):
+        """raise if a kernel met a row index outside its table (include/spp.h spp_async_errors): a peer
+        asked for rows this rank does not own, i.e. the ranks disagree on the partition book"""
+        bits = self.L.spp_async_errors(torch.cuda.current_device(), 1)
+        if bits > 0:
+            raise RuntimeError(f"feature exchange: row index outside its table (async error mask {bits}: "
+                               "1 = gather index, 2 = served id, 4 = assembly source)")
+
     def assemble(self, n_id, perm, seg_start: List[int], P: int, rank: int, rank_offset: int, x_local, recv,
                  cache_feats, cached_nids, recv_base: Optional[List[int]] = None) -> torch.Tensor:
         """recv_base[m]: row of `recv` where peer m's rows for THIS batch start (None: rows packed in
@@ -357,6 +365,9 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         if self.native:
             self._advance(produce_output=True)
         else:
+            check = getattr(self.ops, "check_async", None)
+            if check is not None:
+                check()
             self._fill_next()
         return ret
 
