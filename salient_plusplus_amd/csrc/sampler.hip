@@ -82,7 +82,34 @@ constexpr int kMaxFinePerCoarse = 1 << kMaxFineLog2;
 constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile kernels (more waves per tile: latency bound)
 constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
                                             // one global atomic reserves room for several edges)
+constexpr int kDedupRegs = 6;                // pairs per thread k_bucket_dedup keeps in registers (6 x 256 edges per bucket)
+constexpr int kTileEPT = kBucketTile / kTileNT;  // edges per thread of a tile kernel
+static_assert(kBucketTile % kTileNT == 0, "a tile is a whole number of rounds");
 constexpr uint32_t kPending = 0x80000000u;  // known-list value = kPending | edge position of the previous hop
+
+// Workgroup -> (batch of the group, block within the batch).  Every grouped kernel is launched as a
+// 1-D grid of gx * n workgroups.  interleave = 1: consecutive workgroup ids go to consecutive BATCHES
+// (batch = id % n).  The hardware deals workgroups round-robin over the 8 XCDs, so with n = 8 all
+// workgroups of one batch run on ONE XCD and the batch's scratch arrays (a few MB per hop) are written
+// and re-read through a single L2: scattered 4/8-byte stores merge into whole lines before they
+// leave it and the random re-reads of the next kernel hit.  (Placement is a speed matter only: the
+// results do not depend on it.)  interleave = 0 is the plain batch-major order.
+struct GroupGrid {
+  int32_t first_slot;
+  int32_t n;          // batches in the group
+  uint32_t gx;        // blocks per batch
+  int32_t interleave;
+};
+#define SPP_GROUP_BLOCK(gg)                         \
+  uint32_t bx_, by_;                                \
+  if ((gg).interleave) {                            \
+    by_ = blockIdx.x % (uint32_t)(gg).n;            \
+    bx_ = blockIdx.x / (uint32_t)(gg).n;            \
+  } else {                                          \
+    by_ = blockIdx.x / (gg).gx;                     \
+    bx_ = blockIdx.x - by_ * (gg).gx;               \
+  }                                                 \
+  (void)bx_
 
 // device-resident bookkeeping of one batch slot (copied to pinned host memory after sampling)
 struct SlotState {
@@ -128,6 +155,7 @@ struct SlotPtrs {
 struct GroupArgs {
   int32_t first_slot;
   int32_t n;
+  GroupGrid grid;                  // how this launch's workgroups map to (batch, block)
   int32_t rng_buf;                 // slot ping-pong buffer holding the draws (ignored when rng[i] is set)
   const int64_t* seeds[kMaxGroup];
   int32_t n_seeds[kMaxGroup];
@@ -230,15 +258,16 @@ __global__ __launch_bounds__(256) void k_narrow_col(const int64_t* __restrict__ 
 // seed keeps its LAST position: every seed is appended to its bucket's known list and the LDS
 // insert of known entries takes the max.
 __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g) {
-  const SlotPtrs& s = slots[ga.first_slot + blockIdx.y];
-  const int64_t* __restrict__ seeds = ga.seeds[blockIdx.y];
-  const int32_t n_seeds = ga.n_seeds[blockIdx.y];
-  const int i = blockIdx.x * kNT + threadIdx.x;
+  SPP_GROUP_BLOCK(ga.grid);
+  const SlotPtrs& s = slots[ga.first_slot + by_];
+  const int64_t* __restrict__ seeds = ga.seeds[by_];
+  const int32_t n_seeds = ga.n_seeds[by_];
+  const int i = bx_ * kNT + threadIdx.x;
   if (i == 0) {
     s.st->cnt[0] = n_seeds;
     s.st->dbase[0] = 0;
     s.st->error = 0;
-    s.st->rng = ga.rng[blockIdx.y] ? ga.rng[blockIdx.y] : s.rng[ga.rng_buf];
+    s.st->rng = ga.rng[by_] ? ga.rng[by_] : s.rng[ga.rng_buf];
   }
   if (i < n_seeds) {
     const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
@@ -285,14 +314,15 @@ __device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expect
   return last;
 }
 
-__global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                     const int64_t* __restrict__ rowptr, int32_t h, int32_t f,
                                                     int32_t replace) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds[2][kNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
-  const int64_t i = (int64_t)blockIdx.x * kNT + threadIdx.x;
-  if ((int64_t)blockIdx.x * kNT >= T) return;
+  const int64_t i = (int64_t)bx_ * kNT + threadIdx.x;
+  if ((int64_t)bx_ * kNT >= T) return;
   int32_t cnt = 0, smp = 0;
   if (i < T) {
     const int32_t v = s.n_ids[i];
@@ -307,8 +337,8 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
   block_exclusive_scan<int32_t, kNT>(cnt, lds[0], &tc);
   block_exclusive_scan<int32_t, kNT>(smp, lds[1], &ts);
   if (threadIdx.x == 0) {
-    s.bsum0[blockIdx.x] = tc;
-    s.bsum1[blockIdx.x] = ts;
+    s.bsum0[bx_] = tc;
+    s.bsum1[bx_] = ts;
   }
 }
 
@@ -327,10 +357,11 @@ __device__ int32_t scan_block_sums(int32_t* a, int32_t n, int32_t* lds) {
   return carry;
 }
 
-__global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t h, int32_t f, int32_t ecap, int64_t dcap) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds[kScanNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
   const int32_t nblk = (T + kNT - 1) / kNT;
   const int32_t E = scan_block_sums(s.bsum0, nblk, lds);
@@ -348,23 +379,27 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 // picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
 // ----------------------------------------------------------------------------------------------
 template <bool kGeneric, typename ColT>
-__global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                    const ColT* __restrict__ col, int32_t h, int32_t f,
                                                    int32_t replace) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
-  __shared__ int32_t chosen[kGeneric ? 1 : kFastMaxFanout][kNT];  // Floyd picks, then neighbour ids; column per lane
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  // Floyd picks of the row, one column per lane: f rows of kNT ints, sized by the launch (dynamic LDS) --
+  // a static [32][kNT] array (32 KB) held the kernel to 20 waves per CU whatever the fanout
+  extern __shared__ int32_t chosen_lds[];
+  int32_t (*chosen)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(chosen_lds);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
-  if ((int64_t)blockIdx.x * kNT >= T) return;
-  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  if ((int64_t)bx_ * kNT >= T) return;
+  const int32_t i = bx_ * kNT + threadIdx.x;
   int32_t deg = 0, cnt = 0, smp = 0;
   if (i < T) {
     deg = s.deg[i];
     target_counts(deg, f, replace, cnt, smp);
   }
   int32_t tot;
-  const int32_t p0 = s.bsum0[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot);
-  const int32_t r0 = s.bsum1[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot);
+  const int32_t p0 = s.bsum0[bx_] + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot);
+  const int32_t r0 = s.bsum1[bx_] + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot);
   if (i >= T) return;
   s.out_rowptr[h][i] = p0;
   if (s.st->error) return;
@@ -393,17 +428,27 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   const int tid = threadIdx.x;
   if (smp) {
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
-    // winner = option unless already chosen, then j.
-    for (int32_t k = 0; k < f; ++k) {
-      if (replace) {  // sample_cpu.hpp:79-81
-        chosen[k][tid] = (int32_t)(rng[k] % (uint32_t)deg);
-        continue;
+    // winner = option unless already chosen, then j.  The draws of 8 steps are loaded before the first
+    // of them is used: the steps depend on each other through `chosen`, the loads do not, and under
+    // the delivery kernel's HBM load one global round trip per step was most of this kernel's time.
+    for (int32_t k0 = 0; k0 < f; k0 += 8) {
+      uint32_t r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = (k0 + u < f) ? rng[k0 + u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int32_t k = k0 + u;
+        if (k >= f) break;
+        if (replace) {  // sample_cpu.hpp:79-81
+          chosen[k][tid] = (int32_t)(r[u] % (uint32_t)deg);
+          continue;
+        }
+        const int32_t j = deg - f + k;
+        const int32_t option = (int32_t)(r[u] % (uint32_t)j);
+        bool found = false;
+        for (int32_t m = 0; m < k; ++m) found |= (chosen[m][tid] == option);
+        chosen[k][tid] = found ? j : option;
       }
-      const int32_t j = deg - f + k;
-      const int32_t option = (int32_t)(rng[k] % (uint32_t)j);
-      bool found = false;
-      for (int32_t m = 0; m < k; ++m) found |= (chosen[m][tid] == option);
-      chosen[k][tid] = found ? j : option;
     }
   }
   // neighbour reads in batches of 8 held in registers: the loads of a batch are all issued before the
@@ -423,13 +468,14 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
 
 // generic path: one lane per edge position, row found by binary search in out_rowptr
 template <typename ColT>
-__global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                              const ColT* __restrict__ col, int32_t h, int32_t f,
                                                              int32_t replace) {
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  SPP_GROUP_BLOCK(gg);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
   const int32_t E = s.st->E[h];
-  const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
+  const int64_t p = (int64_t)bx_ * kNT + threadIdx.x;
   if (p >= E) return;
   const int32_t* rp = s.out_rowptr[h];
   int32_t lo = 0, hi = T;  // largest i with rp[i] <= p
@@ -449,23 +495,30 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // ----------------------------------------------------------------------------------------------
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h,
+__global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
                                                       int32_t cb_log2) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lh[kMaxBuckets];
   __shared__ int32_t lscan[kTileNT / kWave + 1];
   __shared__ int is_last;
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t nbk = 1 << cb_log2;  // buckets of THIS hop (coarser than the known lists for small hops)
   const int32_t E = s.st->error ? 0 : s.st->E[h];
-  const int64_t base = (int64_t)blockIdx.x * kBucketTile;
-  if (base >= E && blockIdx.x != 0) return;  // tile 0 always takes part (E may be 0)
+  const int64_t base = (int64_t)bx_ * kBucketTile;
+  if (base >= E && bx_ != 0) return;  // tile 0 always takes part (E may be 0)
   const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
   for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
-    const int64_t p = base + k;
-    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], cb_log2)], 1);
+  // the tile's node ids: every load issued before the first use (kTileEPT independent misses per lane)
+  int32_t v[kTileEPT];
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u) {
+    const int64_t p = base + u * kTileNT + threadIdx.x;
+    v[u] = p < E ? s.cval[p] : -1;  // node ids are >= 0
   }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u)
+    if (v[u] >= 0) atomicAdd(&lh[bucket_of((uint32_t)v[u], cb_log2)], 1);
   __syncthreads();
   for (int b = threadIdx.x; b < nbk; b += kTileNT)
     if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
@@ -492,21 +545,27 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
   if (threadIdx.x == 0) s.boff[nbk] = carry;
 }
 
-__global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                          int32_t h, int32_t cb_log2) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lh[kMaxBuckets];    // tile histogram, then running cursor inside the reservation
   __shared__ int32_t lbase[kMaxBuckets]; // start of this tile's reservation in each bucket
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t nbk = 1 << cb_log2;
   const int32_t E = s.st->E[h];
-  const int64_t base = (int64_t)blockIdx.x * kBucketTile;
+  const int64_t base = (int64_t)bx_ * kBucketTile;
   if (base >= E || s.st->error) return;
   for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
-    const int64_t p = base + k;
-    if (p < E) atomicAdd(&lh[bucket_of((uint32_t)s.cval[p], cb_log2)], 1);
+  int32_t v[kTileEPT];  // loaded once, kept for the scatter pass
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u) {
+    const int64_t p = base + u * kTileNT + threadIdx.x;
+    v[u] = p < E ? s.cval[p] : -1;
   }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u)
+    if (v[u] >= 0) atomicAdd(&lh[bucket_of((uint32_t)v[u], cb_log2)], 1);
   __syncthreads();
   for (int b = threadIdx.x; b < nbk; b += kTileNT) {
     const int32_t c = lh[b];
@@ -514,14 +573,13 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     lh[b] = 0;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < kBucketTile; k += kTileNT) {
-    const int64_t p = base + k;
-    if (p < E) {
-      const uint32_t c = (uint32_t)s.cval[p];
-      const uint32_t b = bucket_of(c, cb_log2);
-      const int32_t j = atomicAdd(&lh[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
-      s.bpairs[lbase[b] + j] = ((unsigned long long)c << 32) | (uint32_t)p;
-    }
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u) {
+    if (v[u] < 0) continue;
+    const uint32_t c = (uint32_t)v[u];
+    const uint32_t b = bucket_of(c, cb_log2);
+    const int32_t j = atomicAdd(&lh[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
+    s.bpairs[lbase[b] + j] = ((unsigned long long)c << 32) | (uint32_t)(base + u * kTileNT + threadIdx.x);
   }
 }
 
@@ -532,19 +590,20 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
 // Every edge gets the final value of its node (evals[p]); the earliest edge of every new node appends
 // (node, kPending | p) to the bucket's known list for the later hops.
 template <int LDS_LOG2>
-__global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t h, DedupGeom g, int32_t cb_log2, int32_t last_hop) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ unsigned long long tab[1 << LDS_LOG2];
   __shared__ int32_t fkc[kMaxFinePerCoarse];   // entries of each fine known list at entry
   __shared__ int32_t fnew[kMaxFinePerCoarse];  // nodes this hop appends to each
   __shared__ int ovf;
   constexpr uint32_t mask = (1u << LDS_LOG2) - 1;
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   if (s.st->error) return;
   // A hop's bucket is a run of 2^shift consecutive fine buckets (bucket ids are top bits of one hash):
   // small hops use few, well-filled workgroups instead of thousands that each set up an LDS table
   // for a handful of edges; the known-node lists stay per FINE bucket for the later, larger hops.
-  const int32_t b = blockIdx.x;
+  const int32_t b = bx_;
   const int32_t shift = g.nb_log2 - cb_log2;
   const int32_t nf = 1 << shift;
   const int32_t fb0 = b << shift;
@@ -567,38 +626,63 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
     unsigned long long* kl = s.known + (int64_t)(fb0 + lf) * g.kcap;
     const int32_t kc = fkc[lf];
-    for (int i = lane; i < kc; i += kWave) {
-      unsigned long long e = kl[i];
-      uint32_t val = (uint32_t)e;
-      if (val & kPending) {
-        val = Tprev + (uint32_t)s.erank[val & ~kPending];
-        e = (e & 0xffffffff00000000ull) | val;
-        kl[i] = e;
+    for (int i0 = lane; i0 < kc; i0 += 4 * kWave) {  // 4 entries per lane and round, loads batched
+      unsigned long long e[4];
+      int32_t rk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kWave;
+        e[u] = i < kc ? kl[i] : kEmptySlot;
       }
-      if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e >> 32), val, &ovf);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t val = (uint32_t)e[u];
+        rk[u] = (e[u] != kEmptySlot && (val & kPending)) ? s.erank[val & ~kPending] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e[u] == kEmptySlot) continue;
+        uint32_t val = (uint32_t)e[u];
+        if (rk[u] >= 0) {
+          val = Tprev + (uint32_t)rk[u];
+          e[u] = (e[u] & 0xffffffff00000000ull) | val;
+          kl[i0 + u * kWave] = e[u];
+        }
+        if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e[u] >> 32), val, &ovf);
+      }
     }
   }
   if (!work) return;
   __syncthreads();
-  for (int i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * kNT) {  // 4 independent loads in flight per lane
-    unsigned long long pr[4];
+  // this hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in registers between
+  // the insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them)
+  unsigned long long pr[kDedupRegs];
+#pragma unroll
+  for (int u = 0; u < kDedupRegs; ++u) {
+    const int i = e0 + u * kNT + threadIdx.x;
+    pr[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
+  }
+#pragma unroll
+  for (int u = 0; u < kDedupRegs; ++u)
+    if (pr[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+  for (int i0 = e0 + kDedupRegs * kNT + threadIdx.x; i0 < e1; i0 += 4 * kNT) {  // oversized bucket: the rest
+    unsigned long long q[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * kNT;
-      pr[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
+      q[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (pr[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+      if (q[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
   }
   __syncthreads();
   if (ovf) {
     if (threadIdx.x == 0) atomicOr(&s.st->error, kErrBucketCap);
     return;
   }
-  for (int i = e0 + threadIdx.x; i < e1; i += kNT) {
-    const unsigned long long pr = s.bpairs[i];
-    const uint32_t key = (uint32_t)(pr >> 32), p = (uint32_t)pr;
+  auto resolve = [&](unsigned long long pair) {
+    const uint32_t key = (uint32_t)(pair >> 32), p = (uint32_t)pair;
     const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
     s.evals[p] = val;
     if (val == T + p && !last_hop) {  // first occurrence of a new node: append to its fine list (no later hop: skip)
@@ -607,7 +691,11 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
       if (j < g.kcap) s.known[(int64_t)(fb0 + lf) * g.kcap + j] = ((unsigned long long)key << 32) | kPending | p;
       else ovf = 1;
     }
-  }
+  };
+#pragma unroll
+  for (int u = 0; u < kDedupRegs; ++u)
+    if (pr[u] != kEmptySlot) resolve(pr[u]);
+  for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(s.bpairs[i]);
   __syncthreads();
   if (threadIdx.x == 0 && ovf) atomicOr(&s.st->error, kErrBucketCap);
   for (int i = threadIdx.x; i < nf; i += kNT) {
@@ -619,24 +707,26 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // first-occurrence ranking
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds[kNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t E = s.st->E[h];
-  if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
+  if ((int64_t)bx_ * kNT >= E || s.st->error) return;
   const uint32_t T = (uint32_t)s.st->cnt[h];
-  const int32_t p = blockIdx.x * kNT + threadIdx.x;
+  const int32_t p = bx_ * kNT + threadIdx.x;
   int32_t flag = 0;
   if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
   int32_t tot;
   block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
-  if (threadIdx.x == 0) s.bsum0[blockIdx.x] = tot;
+  if (threadIdx.x == 0) s.bsum0[bx_] = tot;
 }
 
-__global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                         int32_t h, int32_t f, int32_t ucap) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds[kScanNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   SlotState* st = s.st;
   if (st->error) {
     if (threadIdx.x == 0) {
@@ -656,18 +746,19 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restric
   }
 }
 
-__global__ __launch_bounds__(kNT) void k_hop_assign(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_hop_assign(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                      int32_t h) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds[kNT / kWave + 1];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t E = s.st->E[h];
-  if ((int64_t)blockIdx.x * kNT >= E || s.st->error) return;
+  if ((int64_t)bx_ * kNT >= E || s.st->error) return;
   const uint32_t T = (uint32_t)s.st->cnt[h];
-  const int32_t p = blockIdx.x * kNT + threadIdx.x;
+  const int32_t p = bx_ * kNT + threadIdx.x;
   int32_t flag = 0;
   if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
   int32_t tot;
-  const int32_t r = s.bsum0[blockIdx.x] + block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
+  const int32_t r = s.bsum0[bx_] + block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
   if (p < E) {
     s.erank[p] = r;
     if (flag) {
@@ -684,16 +775,30 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, in
 }
 
 // fast path: one lane per target row, rank sort of <= 32 local ids staged in LDS
-__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t h) {
-  __shared__ int32_t a[kFastMaxFanout][kNT];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
+  SPP_GROUP_BLOCK(gg);
+  extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
+  int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(rows_lds);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
-  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  const int32_t i = bx_ * kNT + threadIdx.x;
   if (i >= T || s.st->error) return;
   const int tid = threadIdx.x;
   const int32_t p0 = s.out_rowptr[h][i];
   const int32_t n = s.out_rowptr[h][i + 1] - p0;
-  for (int32_t k = 0; k < n; ++k) a[k][tid] = local_id_of(s, (uint32_t)T, p0 + k);
+  // local ids of the row, 8 at a time: the table values first, then -- for nodes that are new in
+  // this hop -- the ranks of their first positions; each round's loads are all issued before any use
+  for (int32_t k0 = 0; k0 < n; k0 += 8) {
+    uint32_t v[8];
+    int32_t r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (k0 + u < n) ? s.evals[p0 + k0 + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = (k0 + u < n && v[u] >= (uint32_t)T) ? s.erank[v[u] - (uint32_t)T] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < n) a[k0 + u][tid] = v[u] < (uint32_t)T ? (int32_t)v[u] : T + r[u];
+  }
   int32_t* out = s.out_col[h] + p0;
   for (int32_t k = 0; k < n; ++k) {
     const int32_t v = a[k][tid];
@@ -707,11 +812,12 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
 }
 
 // generic path: local id of every edge position (sorted afterwards by hipcub)
-__global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                            int32_t h) {
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  SPP_GROUP_BLOCK(gg);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t E = s.st->E[h];
-  const int64_t p = (int64_t)blockIdx.x * kNT + threadIdx.x;
+  const int64_t p = (int64_t)bx_ * kNT + threadIdx.x;
   if (p >= E) return;
   s.cval[p] = local_id_of(s, (uint32_t)s.st->cnt[h], (int32_t)p);
 }
@@ -730,15 +836,16 @@ struct PartDev {
   int32_t nblk_cap;  // row pitch of pblk
 };
 
-__global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__ slots, int32_t first_slot, int32_t H,
+__global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t H,
                                                     PartDev a) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t cnt[kPartBuckets];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)blockIdx.x * kNT >= U) return;
+  if ((int64_t)bx_ * kNT >= U) return;
   for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
   __syncthreads();
-  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  const int32_t i = bx_ * kNT + threadIdx.x;
   const bool valid = i < U;
   int32_t b = -1;
   if (valid) {
@@ -757,13 +864,14 @@ __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__
     todo &= ~m;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + blockIdx.x] = cnt[k];
+  for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + bx_] = cnt[k];
 }
 
 // one wavefront per bucket: exclusive scan of the bucket's per-workgroup counts
-__global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                         int32_t H, PartDev a) {
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  SPP_GROUP_BLOCK(gg);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   SlotState* st = s.st;
   const int32_t U = st->error ? 0 : st->cnt[H];
   const int32_t nblk = (U + kNT - 1) / kNT;
@@ -783,13 +891,14 @@ __global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restri
   if (threadIdx.x == 0) st->pcnt[a.P + 1] = 0;  // every local row is HBM resident
 }
 
-__global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t H, PartDev a) {
+  SPP_GROUP_BLOCK(gg);
   __shared__ int32_t wcnt[kNT / kWave][kPartBuckets];
   __shared__ int32_t base[kPartBuckets];
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)blockIdx.x * kNT >= U) return;
+  if ((int64_t)bx_ * kNT >= U) return;
   const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
   for (int k = threadIdx.x; k < (kNT / kWave) * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
   if (threadIdx.x == 0) {
@@ -800,7 +909,7 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
     }
   }
   __syncthreads();
-  const int32_t i = blockIdx.x * kNT + threadIdx.x;
+  const int32_t i = bx_ * kNT + threadIdx.x;
   const bool valid = i < U;
   const int32_t b = valid ? (int32_t)s.pbucket[i] : -1;
   // stable rank inside the wavefront among lanes of the same bucket
@@ -822,7 +931,7 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
   int32_t pre = 0;
   for (int w = 0; w < wid; ++w) pre += wcnt[w][b];
   const int32_t v = s.n_ids[i];
-  const int32_t pos = base[b] + s.pblk[(int64_t)b * a.nblk_cap + blockIdx.x] + pre + rank_w;
+  const int32_t pos = base[b] + s.pblk[(int64_t)b * a.nblk_cap + bx_] + pre + rank_w;
   s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
   if (b < a.P) s.parts[pos] = v;
   else s.pcached[pos - base[a.P]] = a.cache_map[v];  // nid2cachenid (:1256)
@@ -830,14 +939,15 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
 
 // ids requested from the peers, regrouped peer-major across the batches of a group (one send per
 // peer instead of one per peer and batch)
-__global__ __launch_bounds__(kNT) void k_pack_remote_ids(const SlotPtrs* __restrict__ slots, int32_t first_slot,
+__global__ __launch_bounds__(kNT) void k_pack_remote_ids(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                          int32_t P, int32_t rank,
                                                          const int64_t* __restrict__ pack_base,
                                                          int32_t* __restrict__ out) {
-  const SlotPtrs& s = slots[first_slot + blockIdx.y];
+  SPP_GROUP_BLOCK(gg);
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const SlotState* st = s.st;
   if (st->error) return;
-  const int32_t j = blockIdx.x * kNT + threadIdx.x;
+  const int32_t j = bx_ * kNT + threadIdx.x;
   int32_t seg = 0, m = 0;
   for (; m < P; ++m) {
     const int32_t c = st->pcnt[m];
@@ -845,7 +955,7 @@ __global__ __launch_bounds__(kNT) void k_pack_remote_ids(const SlotPtrs* __restr
     seg += c;
   }
   if (m >= P || m == rank) return;
-  out[pack_base[(int64_t)blockIdx.y * P + m] + (j - seg)] = s.parts[j];
+  out[pack_base[(int64_t)by_ * P + m] + (j - seg)] = s.parts[j];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1003,6 +1113,7 @@ struct spp_sampler {
   uint32_t* rng_arena_seeds_dev = nullptr;
   int64_t rng_arena_seeds_cap = 0;
   hipEvent_t rng_arena_ready = nullptr;
+  bool xcd_affinity = true;          // GroupGrid.interleave of the grouped launches (SPP_XCD_AFFINITY=0: batch-major ids)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
   XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
 };
@@ -1049,6 +1160,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
 
   auto* s = new spp_sampler();
   s->cfg = *cfg;
+  if (const char* e = getenv("SPP_XCD_AFFINITY")) s->xcd_affinity = atoi(e) != 0;
   const int H = cfg->num_hops;
   const int64_t node_bound = cfg->num_nodes + cfg->max_batch;  // distinct nodes + duplicated seeds
   s->tcap[0] = cfg->max_batch;
@@ -1077,17 +1189,22 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   // dedup geometry: <= ~1.5k distinct nodes per bucket at the worst case so that a 4096-slot LDS
   // table (32 KB, 4-5 workgroups per CU) stays under 40 % load; larger tables only when the bucket
   // count is capped
+  static const int64_t bucket_nodes = [] {  // worst-case distinct nodes per bucket the geometry aims for
+    const char* e = getenv("SPP_DEDUP_BUCKET");
+    const int64_t v = e ? atoll(e) : 1536;
+    return v < 64 ? 64 : v;
+  }();
   int nb_log2 = 0;
-  while (nb_log2 < kMaxBucketsLog2 && (ucap >> nb_log2) > 1536) ++nb_log2;
+  while (nb_log2 < kMaxBucketsLog2 && (ucap >> nb_log2) > bucket_nodes) ++nb_log2;
   s->geom.nb_log2 = nb_log2;
   s->geom.nb = 1 << nb_log2;
   const int64_t per_bucket = (ucap + s->geom.nb - 1) / s->geom.nb;
   s->geom.kcap = (int32_t)std::min<int64_t>(per_bucket + per_bucket / 2 + 256, 0x7fffffff);
-  s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 2048 ? 13 : 12);
+  s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 2048 ? 13 : (per_bucket > 820 ? 12 : 11));
   for (int h = 0; h < H; ++h) {
     // as few buckets as keep the hop's worst-case node count per bucket within the LDS table's budget
     int c = std::max(0, nb_log2 - kMaxFineLog2);
-    while (c < nb_log2 && (s->tcap[h + 1] >> c) > 1536) ++c;
+    while (c < nb_log2 && (s->tcap[h + 1] >> c) > bucket_nodes) ++c;
     s->cb_log2[h] = c;
   }
   const int nb = s->geom.nb;
@@ -1425,28 +1542,34 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   }
   const unsigned gy = (unsigned)n;
   SlotHost& lead = s->slots[(size_t)first_slot];
+  // batch-interleaved workgroup ids: one batch per XCD when the group has 8 batches (GroupGrid)
+  const int32_t interleave = s->xcd_affinity ? 1 : 0;
+  auto GG = [&](unsigned gx) { return GroupGrid{(int32_t)first_slot, (int32_t)n, gx, interleave}; };
 
   const DedupGeom geom = s->geom;
   // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
   SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
-  hipLaunchKernelGGL(k_seed_init, dim3((unsigned)ceil_div(max_seeds, kNT), gy), dim3(kNT), 0, st, s->d_slots, ga,
-                     geom);
+  const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
+  ga.grid = GG(gseed);
+  hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom);
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
-    hipLaunchKernelGGL(k_hop_count, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, rowptr, h, f, replace);
+    // per-lane row staging of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
+    const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
+    hipLaunchKernelGGL(k_hop_count, dim3((gt) * gy), dim3(kNT), 0, st, s->d_slots, GG(gt), rowptr, h, f, replace);
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
         s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(lead.ecap_dyn[h], 0x7fffffff);
-    hipLaunchKernelGGL(k_hop_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f, ecap_dev, s->dcap);
+    hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
       if (col32)
-        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col32,
-                           h, f, replace);
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, h, f, replace);
       else
-        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h,
-                           f, replace);
+        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col, h, f, replace);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -1456,13 +1579,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       if (lead.host_state->error) break;
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col, h, f,
-                         replace);
+      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
+                         GG(gt), col, h, f, replace);
       if (col32)
-        hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col32,
+        hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col32,
                            h, f, replace);
       else
-        hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, col,
+        hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col,
                            h, f, replace);
     }
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
@@ -1470,25 +1593,27 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
     const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
-    hipLaunchKernelGGL(k_bucket_hist, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(gtile, gy), dim3(kTileNT), 0, st, s->d_slots, first_slot, h, cb);
-    if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
+    hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb);
+    if (s->lds_log2 == 11)
+      hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+    else if (s->lds_log2 == 12)
+      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 13)
-      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else
-      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3(nbk, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h, geom, cb, last);
-    hipLaunchKernelGGL(k_hop_flag, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
-    hipLaunchKernelGGL(k_hop_scan2, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, h, f,
+      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+    hipLaunchKernelGGL(k_hop_flag, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
+    hipLaunchKernelGGL(k_hop_scan2, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f,
                        (int32_t)s->tcap[H]);
-    hipLaunchKernelGGL(k_hop_assign, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+    hipLaunchKernelGGL(k_hop_assign, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_rows, dim3(gt, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];
       if (E > 0) {
-        hipLaunchKernelGGL(k_hop_lids_generic, dim3(ge, gy), dim3(kNT), 0, st, s->d_slots, first_slot, h);
+        hipLaunchKernelGGL(k_hop_lids_generic, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
         size_t need = 0;
         SPP_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, lead.p.cval, lead.p.out_col[h], (int)E, T,
                                                                lead.p.out_rowptr[h], lead.p.out_rowptr[h] + 1, 0, 32,
@@ -1509,9 +1634,9 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   }
   if (s->part.P > 0) {
     const unsigned gu = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[H], kNT));
-    hipLaunchKernelGGL(k_gpart_hist, dim3(gu, gy), dim3(kNT), 0, st, s->d_slots, first_slot, H, s->part);
-    hipLaunchKernelGGL(k_gpart_scan, dim3(1, gy), dim3(kScanNT), 0, st, s->d_slots, first_slot, H, s->part);
-    hipLaunchKernelGGL(k_gpart_scatter, dim3(gu, gy), dim3(kNT), 0, st, s->d_slots, first_slot, H, s->part);
+    hipLaunchKernelGGL(k_gpart_hist, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
+    hipLaunchKernelGGL(k_gpart_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), H, s->part);
+    hipLaunchKernelGGL(k_gpart_scatter, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
   }
   SPP_HIP_TRY(hipGetLastError());
   SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1646,8 +1771,9 @@ spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const 
   SPP_REQUIRE(s->part.P > 0, "sampler_pack_remote_ids: no ownership bucketing");
   SPP_REQUIRE(n >= 1 && first_slot >= 0 && first_slot + n <= (int)s->slots.size(), "sampler_pack_remote_ids: bad slots");
   const unsigned gx = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[s->cfg.num_hops], kNT));
-  hipLaunchKernelGGL(k_pack_remote_ids, dim3(gx, (unsigned)n), dim3(kNT), 0, st, s->d_slots, first_slot, s->part.P,
-                     s->part.rank, pack_base_dev, out_dev);
+  hipLaunchKernelGGL(k_pack_remote_ids, dim3(gx * (unsigned)n), dim3(kNT), 0, st, s->d_slots,
+                     GroupGrid{(int32_t)first_slot, (int32_t)n, gx, s->xcd_affinity ? 1 : 0}, s->part.P, s->part.rank,
+                     pack_base_dev, out_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -91,7 +91,10 @@ def chain_only():
     """Sampling throughput with the consumer side switched off (batches are dropped, never exported)."""
     wl = make_workload(os.environ.get("WL", "S-products"), device=dev)
     torch.cuda.synchronize()
-    for slots, group in ((24, 8), (16, 8), (32, 16), (12, 4)):
+    cfgs = ((24, 8), (16, 8), (32, 16), (12, 4))
+    if os.environ.get("CHAIN_CFG"):          # e.g. CHAIN_CFG=16,8
+        cfgs = (tuple(int(v) for v in os.environ["CHAIN_CFG"].split(",")),)
+    for slots, group in cfgs:
         cfg = nat.SessionCfg()
         cfg.rowptr_dev, cfg.col_dev = wl.rowptr.data_ptr(), wl.col.data_ptr()
         cfg.num_nodes, cfg.nnz = wl.num_nodes, wl.col.numel()
