@@ -82,6 +82,9 @@ constexpr int kMaxFinePerCoarse = 1 << kMaxFineLog2;
 constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile kernels (more waves per tile: latency bound)
 constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
                                             // one global atomic reserves room for several edges)
+constexpr int kScatterTile = 8192;           // edges k_bucket_scatter sorts in LDS per workgroup (48 KB + 8 B per bucket)
+constexpr int kScatterEPT = kScatterTile / kTileNT;
+static_assert(kScatterTile % kTileNT == 0 && kScatterTile <= 65536, "tile-local edge indices are 16 bit");
 constexpr int kDedupRegs = 6;                // pairs per thread k_bucket_dedup keeps in registers (6 x 256 edges per bucket)
 constexpr int kTileEPT = kBucketTile / kTileNT;  // edges per thread of a tile kernel
 static_assert(kBucketTile % kTileNT == 0, "a tile is a whole number of rounds");
@@ -129,6 +132,8 @@ struct SlotPtrs {
   int64_t* rowstart;
   int32_t* cval;       // neighbour node id of every edge position (later: local id, generic path)
   unsigned long long* bpairs;  // edges regrouped by bucket: (node id << 32) | edge position
+  uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order)
+  uint32_t* res;       // table value of every edge, in bucket order (k_bucket_dedup)
   uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
   int32_t* erank;      // exclusive rank among first occurrences (also Floyd scratch, generic path)
   unsigned long long* known;   // [nb][kcap] known nodes per bucket: (node id << 32) | local id (or kPending | pos)
@@ -545,41 +550,80 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
   if (threadIdx.x == 0) s.boff[nbk] = carry;
 }
 
+// Regroups a tile of kScatterTile edges by bucket.  Scattered 8-byte stores leave the L2 as one
+// 32-byte write EACH (plain stores are written through; stores of different waves are never merged:
+// measured 26 B of fabric writes per 8-byte pair), and a million small random writes per batch are what
+// slowed the delivery kernel's streaming traffic most.  So the tile is first bucket-sorted in LDS and
+// then written out in bucket order: consecutive lanes store consecutive pairs of one bucket's run.
+// inv[p] (where edge p went) is stored in position order -- also coalesced -- so that the per-edge
+// results of k_bucket_dedup can stay in bucket order and be fetched back by reads (k_hop_flag).
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                          int32_t h, int32_t cb_log2) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lh[kMaxBuckets];    // tile histogram, then running cursor inside the reservation
-  __shared__ int32_t lbase[kMaxBuckets]; // start of this tile's reservation in each bucket
-  const SlotPtrs& s = slots[gg.first_slot + by_];
+  extern __shared__ int32_t sc_lds[];
   const int32_t nbk = 1 << cb_log2;
+  int32_t* cur = sc_lds;                // [nbk] tile histogram -> running slot cursor of each bucket
+  int32_t* delta = sc_lds + nbk;        // [nbk] (start of the tile's reservation in the bucket) - (first slot of the bucket)
+  uint32_t* snode = reinterpret_cast<uint32_t*>(sc_lds + 2 * nbk);               // [kScatterTile] node ids in bucket order
+  uint16_t* sidx = reinterpret_cast<uint16_t*>(sc_lds + 2 * nbk + kScatterTile);  // [kScatterTile] tile-local edge index
+  __shared__ int32_t lscan[kTileNT / kWave + 1];
+  const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t E = s.st->E[h];
-  const int64_t base = (int64_t)bx_ * kBucketTile;
+  const int64_t base = (int64_t)bx_ * kScatterTile;
   if (base >= E || s.st->error) return;
-  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
-  int32_t v[kTileEPT];  // loaded once, kept for the scatter pass
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) cur[b] = 0;
+  int32_t v[kScatterEPT];  // loaded once, every load in flight before the first use
 #pragma unroll
-  for (int u = 0; u < kTileEPT; ++u) {
+  for (int u = 0; u < kScatterEPT; ++u) {
     const int64_t p = base + u * kTileNT + threadIdx.x;
     v[u] = p < E ? s.cval[p] : -1;
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < kTileEPT; ++u)
-    if (v[u] >= 0) atomicAdd(&lh[bucket_of((uint32_t)v[u], cb_log2)], 1);
+  for (int u = 0; u < kScatterEPT; ++u)
+    if (v[u] >= 0) atomicAdd(&cur[bucket_of((uint32_t)v[u], cb_log2)], 1);
   __syncthreads();
-  for (int b = threadIdx.x; b < nbk; b += kTileNT) {
-    const int32_t c = lh[b];
-    lbase[b] = c ? atomicAdd(&s.bcur[b], c) : 0;
-    lh[b] = 0;
+  // exclusive scan of the tile histogram (first slot of every bucket in the LDS staging order) and
+  // one global reservation per non-empty bucket
+  {
+    const int per = (nbk + kTileNT - 1) / kTileNT;  // consecutive buckets per thread (1..4)
+    const int b0 = threadIdx.x * per;
+    int32_t c[kMaxBuckets / kTileNT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kMaxBuckets / kTileNT; ++k) {
+      c[k] = (k < per && b0 + k < nbk) ? cur[b0 + k] : 0;
+      sum += c[k];
+    }
+    int32_t tot;
+    int32_t off = block_exclusive_scan<int32_t, kTileNT>(sum, lscan, &tot);
+#pragma unroll
+    for (int k = 0; k < kMaxBuckets / kTileNT; ++k) {
+      if (k < per && b0 + k < nbk) {
+        const int32_t g = c[k] ? atomicAdd(&s.bcur[b0 + k], c[k]) : 0;
+        cur[b0 + k] = off;
+        delta[b0 + k] = g - off;
+        off += c[k];
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < kTileEPT; ++u) {
+  for (int u = 0; u < kScatterEPT; ++u) {
     if (v[u] < 0) continue;
     const uint32_t c = (uint32_t)v[u];
     const uint32_t b = bucket_of(c, cb_log2);
-    const int32_t j = atomicAdd(&lh[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
-    s.bpairs[lbase[b] + j] = ((unsigned long long)c << 32) | (uint32_t)(base + u * kTileNT + threadIdx.x);
+    const int32_t slot = atomicAdd(&cur[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
+    const int32_t li = u * kTileNT + threadIdx.x;
+    snode[slot] = c;
+    sidx[slot] = (uint16_t)li;
+    s.inv[base + li] = (uint32_t)(slot + delta[b]);
+  }
+  __syncthreads();
+  const int32_t n_tile = (int32_t)((E - base) < kScatterTile ? (E - base) : kScatterTile);
+  for (int k = threadIdx.x; k < n_tile; k += kTileNT) {
+    const uint32_t c = snode[k];
+    const int32_t dst = k + delta[bucket_of(c, cb_log2)];
+    s.bpairs[dst] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
   }
 }
 
@@ -681,10 +725,10 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     if (threadIdx.x == 0) atomicOr(&s.st->error, kErrBucketCap);
     return;
   }
-  auto resolve = [&](unsigned long long pair) {
+  auto resolve = [&](unsigned long long pair, int i) {
     const uint32_t key = (uint32_t)(pair >> 32), p = (uint32_t)pair;
     const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
-    s.evals[p] = val;
+    s.res[i] = val;  // bucket order: consecutive lanes, consecutive words (k_hop_flag brings it to position order)
     if (val == T + p && !last_hop) {  // first occurrence of a new node: append to its fine list (no later hop: skip)
       const int32_t lf = (int32_t)bucket_of(key, g.nb_log2) - fb0;
       const int j = fkc[lf] + atomicAdd(&fnew[lf], 1);
@@ -694,8 +738,8 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   };
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u)
-    if (pr[u] != kEmptySlot) resolve(pr[u]);
-  for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(s.bpairs[i]);
+    if (pr[u] != kEmptySlot) resolve(pr[u], e0 + u * kNT + threadIdx.x);
+  for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(s.bpairs[i], i);
   __syncthreads();
   if (threadIdx.x == 0 && ovf) atomicOr(&s.st->error, kErrBucketCap);
   for (int i = threadIdx.x; i < nf; i += kNT) {
@@ -716,7 +760,13 @@ __global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ s
   const uint32_t T = (uint32_t)s.st->cnt[h];
   const int32_t p = bx_ * kNT + threadIdx.x;
   int32_t flag = 0;
-  if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
+  if (p < E) {
+    // the dedup results come back to position order by READS (a 4-byte random read of an array that
+    // was just written is served by L2 / Infinity Cache; a 4-byte random write costs a 32-byte HBM write)
+    const uint32_t val = s.res[s.inv[p]];
+    s.evals[p] = val;
+    flag = (val == T + (uint32_t)p) ? 1 : 0;
+  }
   int32_t tot;
   block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
   if (threadIdx.x == 0) s.bsum0[bx_] = tot;
@@ -1288,12 +1338,14 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       hipError_t e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.bpairs, sizeof(unsigned long long) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.inv, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.erank, sizeof(int32_t) * (size_t)etmp);
       if (e != hipSuccess) {
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
       }
-      s->bytes += 20 * etmp;
+      s->bytes += 28 * etmp;
     }
     if (rc == SPP_OK && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
       set_error("spp_sampler_create: hipEventCreate failed");
@@ -1329,6 +1381,20 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       }
     }
   }
+  if (rc == SPP_OK) {
+    // k_bucket_scatter stages a tile in up to 80 KB of dynamic LDS (gfx950: 160 KB per CU and per workgroup)
+    const int need = (int)(sizeof(int32_t) * 2 * kMaxBuckets + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
+    int have = 0;
+    (void)hipDeviceGetAttribute(&have, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device);
+    if (have < need + 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bucket_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            need) != hipSuccess) {
+      set_error("spp_sampler_create: the device offers %d bytes of LDS per workgroup, k_bucket_scatter needs %d "
+                "(this library targets gfx950)", have, need + 1024);
+      (void)hipGetLastError();
+      rc = SPP_ERR_HIP;
+    }
+  }
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
   if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) {
     set_error("spp_sampler_create: stream creation failed");
@@ -1359,6 +1425,8 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.p.cval) (void)hipFree(sl.p.cval);
     if (sl.p.bpairs) (void)hipFree(sl.p.bpairs);
     if (sl.p.evals) (void)hipFree(sl.p.evals);
+    if (sl.p.inv) (void)hipFree(sl.p.inv);
+    if (sl.p.res) (void)hipFree(sl.p.res);
     if (sl.p.erank) (void)hipFree(sl.p.erank);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
@@ -1399,14 +1467,18 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
     int32_t* old_erank = sl.p.erank;
     const int64_t old_cap = sl.etmp_cap;
     (void)hipFree(sl.p.cval); (void)hipFree(sl.p.bpairs); (void)hipFree(sl.p.evals);
+    (void)hipFree(sl.p.inv); (void)hipFree(sl.p.res);
     sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.erank = nullptr;
+    sl.p.inv = nullptr; sl.p.res = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.inv, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.erank, sizeof(int32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMemcpy(sl.p.erank, old_erank, sizeof(int32_t) * (size_t)old_cap, hipMemcpyDeviceToDevice));
     (void)hipFree(old_erank);
-    s->bytes += 20 * (cap - sl.etmp_cap);
+    s->bytes += 28 * (cap - sl.etmp_cap);
     sl.etmp_cap = cap;
     changed = true;
   }
@@ -1594,7 +1666,9 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned nbk = 1u << cb;
     const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
     hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb);
+    const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
+    const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb);
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 12)
