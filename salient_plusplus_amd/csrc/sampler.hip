@@ -18,13 +18,15 @@
 //   k_hop_pick      lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
 //                                 col reads -> neighbour id of every edge position
 //   k_bucket_hist   tile/16k edges: edges per node-hash bucket; the last tile scans -> bucket offsets
-//   k_bucket_scatter tile       : (node, position) pairs regrouped by bucket (sequential traffic)
+//   k_bucket_scatter tile/8k edges: tile bucket-sorted in LDS, (node, position) pairs written out as
+//                                 coalesced bucket runs; inv[p] = where edge p went
 //   k_bucket_dedup  workgroup/bucket: LDS table of the bucket's known nodes + candidates ->
-//                                 per edge: final local id, or T + earliest position of a new node
-//   k_hop_flag      lane/edge   : "is first occurrence" flags, workgroup flag sums
-//   k_hop_scan2     1 workgroup : scan of flag sums -> number of new nodes
-//   k_hop_assign    lane/edge   : rank of every first occurrence -> new local id, n_ids append
-//   k_hop_rows      lane/target : local ids of the row, LDS rank-sort, out_col
+//                                 per edge (bucket order): final local id, or T + earliest position of a new node
+//   k_hop_flag      lane/edge   : results back to position order by reads (res[inv[p]]); bitmap of
+//                                 first occurrences + per-word / per-block counts
+//   k_hop_scan2     1 workgroup : scan of the block counts -> number of new nodes
+//   k_hop_rows      lane/target : local ids of the row (rank of a new node = prefix + popcount of the
+//                                 bitmap), n_ids append at first occurrences, LDS rank-sort, out_col
 // The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
 // one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
 // the ~0.5 ms serial recurrence never sits on the sampling critical path.
@@ -135,7 +137,13 @@ struct SlotPtrs {
   uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order)
   uint32_t* res;       // table value of every edge, in bucket order (k_bucket_dedup)
   uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
-  int32_t* erank;      // exclusive rank among first occurrences (also Floyd scratch, generic path)
+  // first occurrences of the hop (new nodes), by edge position: a bitmap, the number of set bits in the
+  // earlier words of the same 256-position block, and the exclusive prefix of the blocks' totals.
+  // rank(q) = fsum[q >> 8] + wpre[q >> 6] + popcount(fbits[q >> 6] below bit q & 63): three reads of arrays
+  // that stay in L2 (E/8 + E/32 + E/64 bytes) replace a 4-byte rank per edge position.
+  unsigned long long* fbits;
+  uint16_t* wpre;
+  int32_t* fsum;
   unsigned long long* known;   // [nb][kcap] known nodes per bucket: (node id << 32) | local id (or kPending | pos)
   int32_t* kcount;     // [nb] entries in each known list
   int32_t* bcount;     // [nb] edges per bucket of the current hop (zero between hops)
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   const uint32_t* rng = s.st->rng;
   if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
   if (kGeneric) {
-    // only the Floyd picks are produced here (into evals[p0..p0+f), free at this point; erank still
-    // holds the previous hop's ranks, needed by k_bucket_dedup); expansion is edge-parallel
+    // only the Floyd picks are produced here (into evals[p0..p0+f), free at this point);
+    // expansion is edge-parallel
     if (smp) {
       int32_t* mine = reinterpret_cast<int32_t*>(s.evals) + p0;
       for (int32_t k = 0; k < f; ++k) {
@@ -627,6 +635,13 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
   }
 }
 
+// exclusive rank of edge position q among the hop's first occurrences (q must be one, or any position
+// when only "first occurrences before q" is wanted)
+__device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
+  const uint32_t w = q >> 6;
+  return s.fsum[q >> 8] + (int32_t)s.wpre[w] + __popcll(s.fbits[w] & ((1ull << (q & 63)) - 1ull));
+}
+
 // One workgroup per bucket: known nodes (ids from earlier hops; pending ones of the previous hop are
 // resolved through its rank array first) and this hop's candidates meet in an LDS table.
 //   value < T          : final local id of an already known node
@@ -663,8 +678,8 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
   if (threadIdx.x == 0) ovf = 0;
   __syncthreads();
-  // known nodes: resolve the previous hop's pending ids (its rank array is overwritten by this hop's
-  // k_hop_assign, so this must happen now for EVERY list), then publish them in the LDS table;
+  // known nodes: resolve the previous hop's pending ids (its first-occurrence bitmap is overwritten by
+  // this hop's k_hop_flag, so this must happen now for EVERY list), then publish them in the LDS table;
   // one wavefront per fine list
   const int lane = threadIdx.x & (kWave - 1);
   for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
@@ -681,7 +696,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t val = (uint32_t)e[u];
-        rk[u] = (e[u] != kEmptySlot && (val & kPending)) ? s.erank[val & ~kPending] : -1;
+        rk[u] = (e[u] != kEmptySlot && (val & kPending)) ? first_rank(s, val & ~kPending) : -1;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -753,23 +768,33 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lds[kNT / kWave + 1];
+  static_assert(kNT == 4 * kWave, "a block of positions is four bitmap words");
+  __shared__ int32_t wcnt[kNT / kWave];
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t E = s.st->E[h];
   if ((int64_t)bx_ * kNT >= E || s.st->error) return;
   const uint32_t T = (uint32_t)s.st->cnt[h];
   const int32_t p = bx_ * kNT + threadIdx.x;
-  int32_t flag = 0;
+  bool flag = false;
   if (p < E) {
     // the dedup results come back to position order by READS (a 4-byte random read of an array that
     // was just written is served by L2 / Infinity Cache; a 4-byte random write costs a 32-byte HBM write)
     const uint32_t val = s.res[s.inv[p]];
     s.evals[p] = val;
-    flag = (val == T + (uint32_t)p) ? 1 : 0;
+    flag = (val == T + (uint32_t)p);  // first occurrence of a node that is new in this hop
   }
-  int32_t tot;
-  block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
-  if (threadIdx.x == 0) s.bsum0[bx_] = tot;
+  const unsigned long long bits = __ballot(flag);
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  if (lane == 0) wcnt[wid] = __popcll(bits);
+  __syncthreads();
+  if (lane == 0) {
+    int32_t pre = 0;
+    for (int w = 0; w < wid; ++w) pre += wcnt[w];
+    const int64_t word = (int64_t)bx_ * (kNT / kWave) + wid;
+    s.fbits[word] = bits;
+    s.wpre[word] = (uint16_t)pre;
+    if (wid == kNT / kWave - 1) s.fsum[bx_] = pre + wcnt[wid];  // block total; k_hop_scan2 turns it into a prefix
+  }
 }
 
 __global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restrict__ slots, GroupGrid gg,
@@ -787,7 +812,7 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restric
   }
   const int32_t E = st->E[h];
   const int32_t nblk = (E + kNT - 1) / kNT;
-  const int32_t nnew = scan_block_sums(s.bsum0, nblk, lds);
+  const int32_t nnew = scan_block_sums(s.fsum, nblk, lds);
   if (threadIdx.x == 0) {
     const int32_t U = st->cnt[h] + nnew;
     st->cnt[h + 1] = U;
@@ -796,35 +821,14 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restric
   }
 }
 
-__global__ __launch_bounds__(kNT) void k_hop_assign(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                     int32_t h) {
-  SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lds[kNT / kWave + 1];
-  const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t E = s.st->E[h];
-  if ((int64_t)bx_ * kNT >= E || s.st->error) return;
-  const uint32_t T = (uint32_t)s.st->cnt[h];
-  const int32_t p = bx_ * kNT + threadIdx.x;
-  int32_t flag = 0;
-  if (p < E) flag = (s.evals[p] == T + (uint32_t)p) ? 1 : 0;
-  int32_t tot;
-  const int32_t r = s.bsum0[bx_] + block_exclusive_scan<int32_t, kNT>(flag, lds, &tot);
-  if (p < E) {
-    s.erank[p] = r;
-    if (flag) {
-      const int32_t c = s.cval[p];
-      const uint32_t id = T + (uint32_t)r;
-      s.n_ids[id] = c;  // n_ids.push_back(c); the known lists resolve this id lazily (kPending)
-    }
-  }
+// local id behind a table value: final ids are below T; T + q names the node first reached at edge position q
+__device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, uint32_t v) {
+  return (v < T) ? (int32_t)v : (int32_t)T + first_rank(s, v - T);
 }
 
-__device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, int32_t p) {
-  const uint32_t v = s.evals[p];
-  return (v < T) ? (int32_t)v : (int32_t)(T + (uint32_t)s.erank[v - T]);
-}
-
-// fast path: one lane per target row, rank sort of <= 32 local ids staged in LDS
+// fast path: one lane per target row.  Local ids of the row's edges (rank lookups for the nodes that
+// are new in this hop), n_ids.push_back for the row's first occurrences (sample_cpu.hpp:50-60), rank
+// sort of the <= 32 ids staged in LDS (sample_cpu.hpp:126).
 __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
@@ -836,18 +840,35 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
   const int tid = threadIdx.x;
   const int32_t p0 = s.out_rowptr[h][i];
   const int32_t n = s.out_rowptr[h][i + 1] - p0;
-  // local ids of the row, 8 at a time: the table values first, then -- for nodes that are new in
-  // this hop -- the ranks of their first positions; each round's loads are all issued before any use
+  // 8 edges at a time; each round's loads are all issued before any of them is used
   for (int32_t k0 = 0; k0 < n; k0 += 8) {
-    uint32_t v[8];
-    int32_t r[8];
+    uint32_t v[8], q[8];
+    int32_t c[8], fs[8], wp[8];
+    unsigned long long fb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = (k0 + u < n) ? s.evals[p0 + k0 + u] : 0u;
+    for (int u = 0; u < 8; ++u) {
+      const bool on = k0 + u < n;
+      v[u] = on ? s.evals[p0 + k0 + u] : 0u;
+      c[u] = on ? s.cval[p0 + k0 + u] : 0;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = (k0 + u < n && v[u] >= (uint32_t)T) ? s.erank[v[u] - (uint32_t)T] : 0;
+    for (int u = 0; u < 8; ++u) {
+      const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
+      q[u] = fresh ? v[u] - (uint32_t)T : 0u;
+      fs[u] = fresh ? s.fsum[q[u] >> 8] : 0;
+      wp[u] = fresh ? (int32_t)s.wpre[q[u] >> 6] : 0;
+      fb[u] = fresh ? s.fbits[q[u] >> 6] : 0ull;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (k0 + u < n) a[k0 + u][tid] = v[u] < (uint32_t)T ? (int32_t)v[u] : T + r[u];
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u >= n) break;
+      int32_t id = (int32_t)v[u];
+      if (v[u] >= (uint32_t)T) {
+        id = T + fs[u] + wp[u] + __popcll(fb[u] & ((1ull << (q[u] & 63)) - 1ull));
+        if (q[u] == (uint32_t)(p0 + k0 + u)) s.n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
+      }
+      a[k0 + u][tid] = id;
+    }
   }
   int32_t* out = s.out_col[h] + p0;
   for (int32_t k = 0; k < n; ++k) {
@@ -869,7 +890,11 @@ __global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __rest
   const int32_t E = s.st->E[h];
   const int64_t p = (int64_t)bx_ * kNT + threadIdx.x;
   if (p >= E) return;
-  s.cval[p] = local_id_of(s, (uint32_t)s.st->cnt[h], (int32_t)p);
+  const uint32_t T = (uint32_t)s.st->cnt[h];
+  const uint32_t v = s.evals[p];
+  const int32_t id = local_id_of(s, T, v);
+  if (v == T + (uint32_t)p) s.n_ids[id] = s.cval[p];  // n_ids.push_back(c) at the node's first occurrence
+  s.cval[p] = id;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1168,6 +1193,13 @@ struct spp_sampler {
   XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
 };
 
+// layout of a slot's first-occurrence rank arrays for `cap` edge positions: [fbits | wpre | fsum] in one allocation
+static inline int64_t rank_words(int64_t cap) { return cap / 64 + 4; }
+static inline int64_t rank_blocks(int64_t cap) { return cap / 256 + 4; }
+static inline size_t rank_off_wpre(int64_t cap) { return (size_t)(8 * rank_words(cap)); }
+static inline size_t rank_off_fsum(int64_t cap) { return (rank_off_wpre(cap) + (size_t)(2 * rank_words(cap)) + 15) & ~(size_t)15; }
+static inline size_t rank_bytes(int64_t cap) { return rank_off_fsum(cap) + (size_t)(4 * rank_blocks(cap)); }
+
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
   if (bytes == 0) bytes = 16;
   SPP_HIP_TRY(hipMalloc(out, bytes));
@@ -1340,12 +1372,16 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.inv, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * (size_t)etmp);
-      if (e == hipSuccess) e = hipMalloc((void**)&p.erank, sizeof(int32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.fbits, rank_bytes(etmp));
+      if (e == hipSuccess) {
+        p.wpre = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.fbits) + rank_off_wpre(etmp));
+        p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p.fbits) + rank_off_fsum(etmp));
+      }
       if (e != hipSuccess) {
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
       }
-      s->bytes += 28 * etmp;
+      s->bytes += 24 * etmp + (int64_t)rank_bytes(etmp);
     }
     if (rc == SPP_OK && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
       set_error("spp_sampler_create: hipEventCreate failed");
@@ -1427,7 +1463,7 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.p.evals) (void)hipFree(sl.p.evals);
     if (sl.p.inv) (void)hipFree(sl.p.inv);
     if (sl.p.res) (void)hipFree(sl.p.res);
-    if (sl.p.erank) (void)hipFree(sl.p.erank);
+    if (sl.p.fbits) (void)hipFree(sl.p.fbits);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
   if (s->rng_arena) (void)hipFree(s->rng_arena);
@@ -1463,22 +1499,28 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
   bool changed = false;
   if (need > sl.etmp_cap) {
     int64_t cap = std::max(need, sl.etmp_cap * 2);
-    // erank is preserved: it still holds the previous hop's ranks, which k_bucket_dedup needs
-    int32_t* old_erank = sl.p.erank;
+    // the rank arrays are preserved: they still describe the previous hop, which k_bucket_dedup needs
+    unsigned long long* old_fbits = sl.p.fbits;
+    uint16_t* old_wpre = sl.p.wpre;
+    int32_t* old_fsum = sl.p.fsum;
     const int64_t old_cap = sl.etmp_cap;
     (void)hipFree(sl.p.cval); (void)hipFree(sl.p.bpairs); (void)hipFree(sl.p.evals);
     (void)hipFree(sl.p.inv); (void)hipFree(sl.p.res);
-    sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.erank = nullptr;
+    sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.fbits = nullptr;
     sl.p.inv = nullptr; sl.p.res = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.inv, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMalloc((void**)&sl.p.erank, sizeof(int32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMemcpy(sl.p.erank, old_erank, sizeof(int32_t) * (size_t)old_cap, hipMemcpyDeviceToDevice));
-    (void)hipFree(old_erank);
-    s->bytes += 28 * (cap - sl.etmp_cap);
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.fbits, rank_bytes(cap)));
+    sl.p.wpre = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(sl.p.fbits) + rank_off_wpre(cap));
+    sl.p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sl.p.fbits) + rank_off_fsum(cap));
+    SPP_HIP_TRY(hipMemcpy(sl.p.fbits, old_fbits, 8 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
+    SPP_HIP_TRY(hipMemcpy(sl.p.wpre, old_wpre, 2 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
+    SPP_HIP_TRY(hipMemcpy(sl.p.fsum, old_fsum, 4 * (size_t)rank_blocks(old_cap), hipMemcpyDeviceToDevice));
+    (void)hipFree(old_fbits);
+    s->bytes += 24 * (cap - sl.etmp_cap) + (int64_t)rank_bytes(cap) - (int64_t)rank_bytes(sl.etmp_cap);
     sl.etmp_cap = cap;
     changed = true;
   }
@@ -1680,7 +1722,6 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     hipLaunchKernelGGL(k_hop_flag, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
     hipLaunchKernelGGL(k_hop_scan2, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f,
                        (int32_t)s->tcap[H]);
-    hipLaunchKernelGGL(k_hop_assign, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
     if (!s->generic[h]) {
       hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
     } else {
