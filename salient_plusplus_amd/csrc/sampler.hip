@@ -14,17 +14,19 @@
 // the batch slot) so that even the small first hops put >> 256 workgroups on the chip.  Per hop
 // (T = nodes collected so far = targets; all counts stay on the device):
 //   k_hop_count     lane/target : rowptr -> deg, row_start; per-workgroup sums of (#edges, #sampled)
-//   k_hop_scan      1 workgroup : scan of the workgroup sums -> E_h, #sampled, capacity checks
-//   k_hop_pick      lane/target : prefix sums -> out_rowptr[i], RNG offset; Floyd picks staged in LDS;
+//                                 (hop 0: done by k_seed_init)
+//   k_hop_pick      lane/target : sums of the workgroups before its own -> out_rowptr[i], RNG offset
+//                                 (the last workgroup records E_h, #sampled); Floyd picks staged in LDS;
 //                                 col reads -> neighbour id of every edge position
+//                                 (k_hop_scan: single-workgroup scan instead, generic / very large hops)
 //   k_bucket_hist   tile/16k edges: edges per node-hash bucket; the last tile scans -> bucket offsets
 //   k_bucket_scatter tile/8k edges: tile bucket-sorted in LDS, (node, position) pairs written out as
 //                                 coalesced bucket runs; inv[p] = where edge p went
 //   k_bucket_dedup  workgroup/bucket: LDS table of the bucket's known nodes + candidates ->
 //                                 per edge (bucket order): final local id, or T + earliest position of a new node
-//   k_hop_flag      lane/edge   : results back to position order by reads (res[inv[p]]); bitmap of
-//                                 first occurrences + per-word / per-block counts
-//   k_hop_scan2     1 workgroup : scan of the block counts -> number of new nodes
+//   k_hop_flag      4 edges/lane: results back to position order by reads (res[inv[p]]); bitmap of
+//                                 first occurrences + per-word / per-block counts; the last workgroup
+//                                 (ticket) scans the block counts -> number of new nodes
 //   k_hop_rows      lane/target : local ids of the row (rank of a new node = prefix + popcount of the
 //                                 bitmap), n_ids append at first occurrences, LDS rank-sort, out_col
 // The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
@@ -267,34 +269,6 @@ __global__ __launch_bounds__(256) void k_narrow_col(const int64_t* __restrict__ 
     out[i] = (int32_t)col[i];
 }
 
-// get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
-// seed keeps its LAST position: every seed is appended to its bucket's known list and the LDS
-// insert of known entries takes the max.
-__global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g) {
-  SPP_GROUP_BLOCK(ga.grid);
-  const SlotPtrs& s = slots[ga.first_slot + by_];
-  const int64_t* __restrict__ seeds = ga.seeds[by_];
-  const int32_t n_seeds = ga.n_seeds[by_];
-  const int i = bx_ * kNT + threadIdx.x;
-  if (i == 0) {
-    s.st->cnt[0] = n_seeds;
-    s.st->dbase[0] = 0;
-    s.st->error = 0;
-    s.st->rng = ga.rng[by_] ? ga.rng[by_] : s.rng[ga.rng_buf];
-  }
-  if (i < n_seeds) {
-    const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
-    s.n_ids[i] = v;
-    const uint32_t b = bucket_of((uint32_t)v, g.nb_log2);
-    const int32_t j = atomicAdd(&s.kcount[b], 1);
-    if (j < g.kcap) s.known[(int64_t)b * g.kcap + j] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)i;
-    else atomicOr(&s.st->error, kErrBucketCap);
-  }
-}
-
-// ----------------------------------------------------------------------------------------------
-// per-target degree pass
-// ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t replace, int32_t& cnt, int32_t& smp) {
   if (replace && f >= 0) {
     // with replacement (sample_cpu.hpp:74-82): f draws of gen() % deg whenever deg > 0
@@ -306,6 +280,54 @@ __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t re
   smp = (f >= 0 && deg > f) ? 1 : 0;
   cnt = smp ? f : (deg > 0 ? deg : 0);
 }
+
+// get_initial_sample_adj_hash_map (sample_cpu.hpp:13-19): n_id_map[n_ids[i]] = i, so a duplicated
+// seed keeps its LAST position: every seed is appended to its bucket's known list and the LDS
+// insert of known entries takes the max.
+// Also the degree pass of hop 0 (k_hop_count with h = 0: the targets are the seeds themselves), so a
+// chain starts with one launch instead of two.
+__global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g,
+                                                    const int64_t* __restrict__ rowptr, int32_t f, int32_t replace) {
+  SPP_GROUP_BLOCK(ga.grid);
+  __shared__ int32_t lds[2][kNT / kWave + 1];
+  const SlotPtrs& s = slots[ga.first_slot + by_];
+  const int64_t* __restrict__ seeds = ga.seeds[by_];
+  const int32_t n_seeds = ga.n_seeds[by_];
+  const int i = bx_ * kNT + threadIdx.x;
+  if ((int64_t)bx_ * kNT >= n_seeds && bx_ != 0) return;
+  if (i == 0) {
+    s.st->cnt[0] = n_seeds;
+    s.st->dbase[0] = 0;
+    s.st->error = 0;
+    s.st->rng = ga.rng[by_] ? ga.rng[by_] : s.rng[ga.rng_buf];
+  }
+  int32_t cnt = 0, smp = 0;
+  if (i < n_seeds) {
+    const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
+    const int64_t rs = rowptr[v];
+    const int64_t re = rowptr[v + 1];
+    s.n_ids[i] = v;
+    const uint32_t b = bucket_of((uint32_t)v, g.nb_log2);
+    const int32_t j = atomicAdd(&s.kcount[b], 1);
+    if (j < g.kcap) s.known[(int64_t)b * g.kcap + j] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)i;
+    else atomicOr(&s.st->error, kErrBucketCap);
+    const int32_t deg = (int32_t)(re - rs);
+    s.deg[i] = deg;
+    s.rowstart[i] = rs;
+    target_counts(deg, f, replace, cnt, smp);
+  }
+  int32_t tc, ts;
+  block_exclusive_scan<int32_t, kNT>(cnt, lds[0], &tc);
+  block_exclusive_scan<int32_t, kNT>(smp, lds[1], &ts);
+  if (threadIdx.x == 0) {
+    s.bsum0[bx_] = tc;
+    s.bsum1[bx_] = ts;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// per-target degree pass
+// ----------------------------------------------------------------------------------------------
 
 // ---- "last workgroup finishes the job" ---------------------------------------------------------
 // Producer workgroups publish partial results with device-scope atomics, drain them (s_waitcnt
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 template <bool kGeneric, typename ColT>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                    const ColT* __restrict__ col, int32_t h, int32_t f,
-                                                   int32_t replace) {
+                                                   int32_t replace, int32_t self_prefix, int32_t ecap, int64_t dcap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   // Floyd picks of the row, one column per lane: f rows of kNT ints, sized by the launch (dynamic LDS) --
@@ -403,17 +425,43 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   int32_t (*chosen)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(chosen_lds);
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
-  if ((int64_t)bx_ * kNT >= T) return;
+  if ((int64_t)bx_ * kNT >= T && bx_ != 0) return;  // workgroup 0 always runs: it records the totals of an empty hop
   const int32_t i = bx_ * kNT + threadIdx.x;
   int32_t deg = 0, cnt = 0, smp = 0;
   if (i < T) {
     deg = s.deg[i];
     target_counts(deg, f, replace, cnt, smp);
   }
-  int32_t tot;
-  const int32_t p0 = s.bsum0[bx_] + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot);
-  const int32_t r0 = s.bsum1[bx_] + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot);
+  // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
+  // workgroup adds up their per-workgroup sums (k_hop_count) itself -- at most a few loads per lane --
+  // instead of a single-workgroup scan kernel between the two launches; the last workgroup records the
+  // hop's totals.  (Without: bsum0/bsum1 were scanned in place by k_hop_scan.)
+  int32_t pre0, pre1, tot0, tot1;
+  if (self_prefix) {
+    int32_t a0 = 0, a1 = 0;
+    for (int k = threadIdx.x; k < (int)bx_; k += kNT) {
+      a0 += s.bsum0[k];
+      a1 += s.bsum1[k];
+    }
+    block_exclusive_scan<int32_t, kNT>(a0, lds_scan[0], &pre0);
+    block_exclusive_scan<int32_t, kNT>(a1, lds_scan[1], &pre1);
+    __syncthreads();  // lds_scan is reused below
+  } else {
+    pre0 = s.bsum0[bx_];
+    pre1 = s.bsum1[bx_];
+  }
+  const int32_t p0 = pre0 + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot0);
+  const int32_t r0 = pre1 + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot1);
+  if (self_prefix && threadIdx.x == 0 && (int64_t)(bx_ + 1) * kNT >= T) {  // the last workgroup with targets
+    const int32_t E = pre0 + tot0, S = pre1 + tot1;
+    s.st->E[h] = E;
+    s.st->nsmp[h] = S;
+    s.out_rowptr[h][T] = E;
+    if (E > ecap) atomicOr(&s.st->error, kErrEdgeCap);
+    if (s.st->dbase[h] + (int64_t)(f > 0 ? f : 0) * S > dcap) atomicOr(&s.st->error, kErrDrawCap);
+  }
   if (i >= T) return;
+  if (self_prefix && (p0 + cnt > ecap || (smp && s.st->dbase[h] + (int64_t)f * (r0 + 1) > dcap))) return;  // see above
   s.out_rowptr[h][i] = p0;
   if (s.st->error) return;
   const uint32_t* rng = s.st->rng;
@@ -766,53 +814,98 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // first-occurrence ranking
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
-  SPP_GROUP_BLOCK(gg);
-  static_assert(kNT == 4 * kWave, "a block of positions is four bitmap words");
-  __shared__ int32_t wcnt[kNT / kWave];
-  const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t E = s.st->E[h];
-  if ((int64_t)bx_ * kNT >= E || s.st->error) return;
-  const uint32_t T = (uint32_t)s.st->cnt[h];
-  const int32_t p = bx_ * kNT + threadIdx.x;
-  bool flag = false;
-  if (p < E) {
-    // the dedup results come back to position order by READS (a 4-byte random read of an array that
-    // was just written is served by L2 / Infinity Cache; a 4-byte random write costs a 32-byte HBM write)
-    const uint32_t val = s.res[s.inv[p]];
-    s.evals[p] = val;
-    flag = (val == T + (uint32_t)p);  // first occurrence of a node that is new in this hop
+// scan_block_sums for sums that other workgroups of the SAME launch stored with agent-scope stores
+__device__ int32_t scan_block_sums_acquire(int32_t* a, int32_t n, int32_t* lds) {
+  int32_t carry = 0;
+  for (int32_t base = 0; base < n; base += kScanNT) {
+    const int32_t i = base + threadIdx.x;
+    const int32_t v = (i < n) ? acquire_i32(&a[i]) : 0;
+    int32_t tot;
+    const int32_t ex = block_exclusive_scan<int32_t, kScanNT>(v, lds, &tot);
+    if (i < n) a[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
   }
-  const unsigned long long bits = __ballot(flag);
-  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  if (lane == 0) wcnt[wid] = __popcll(bits);
-  __syncthreads();
-  if (lane == 0) {
-    int32_t pre = 0;
-    for (int w = 0; w < wid; ++w) pre += wcnt[w];
-    const int64_t word = (int64_t)bx_ * (kNT / kWave) + wid;
-    s.fbits[word] = bits;
-    s.wpre[word] = (uint16_t)pre;
-    if (wid == kNT / kWave - 1) s.fsum[bx_] = pre + wcnt[wid];  // block total; k_hop_scan2 turns it into a prefix
-  }
+  return carry;
 }
 
-__global__ __launch_bounds__(kScanNT) void k_hop_scan2(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                        int32_t h, int32_t f, int32_t ucap) {
+constexpr int kFlagNT = 1024;                   // workgroup of k_hop_flag
+constexpr int kFlagRounds = 4;                  // positions per thread
+constexpr int kFlagSpan = kFlagNT * kFlagRounds;  // positions per workgroup = 64 bitmap words = 16 blocks of 256
+static_assert(kFlagNT == kScanNT, "the last workgroup scans with its own threads");
+
+// Per edge position p: the table value of its node back in position order (reads of res through inv:
+// a 4-byte random READ of a just-written array is served by L2 / Infinity Cache, a 4-byte random
+// write would cost a 32-byte HBM write), the first-occurrence bitmap and its per-word / per-block
+// counts.  The workgroup that finishes last (device-scope ticket) turns the block counts into the
+// exclusive prefix and records the hop's node count -- no separate scan launch.
+__global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
+                                                       int32_t f, int32_t ucap) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lds[kScanNT / kWave + 1];
+  __shared__ int32_t wcnt[kFlagRounds][kFlagNT / kWave];
+  __shared__ int32_t lscan[kScanNT / kWave + 1];
+  __shared__ int is_last;
   const SlotPtrs& s = slots[gg.first_slot + by_];
   SlotState* st = s.st;
   if (st->error) {
-    if (threadIdx.x == 0) {
+    if (bx_ == 0 && threadIdx.x == 0) {  // keep the later hops' sizes defined
       st->cnt[h + 1] = st->cnt[h];
       st->dbase[h + 1] = st->dbase[h];
     }
     return;
   }
   const int32_t E = st->E[h];
-  const int32_t nblk = (E + kNT - 1) / kNT;
-  const int32_t nnew = scan_block_sums(s.fsum, nblk, lds);
+  const int32_t nwg = E > 0 ? (E + kFlagSpan - 1) / kFlagSpan : 1;  // workgroup 0 always takes part
+  if ((int32_t)bx_ >= nwg) return;
+  const uint32_t T = (uint32_t)st->cnt[h];
+  const int64_t base = (int64_t)bx_ * kFlagSpan;
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  uint32_t slot[kFlagRounds];
+#pragma unroll
+  for (int r = 0; r < kFlagRounds; ++r) {
+    const int64_t p = base + r * kFlagNT + threadIdx.x;
+    slot[r] = p < E ? s.inv[p] : 0u;
+  }
+  uint32_t val[kFlagRounds];
+#pragma unroll
+  for (int r = 0; r < kFlagRounds; ++r) {
+    const int64_t p = base + r * kFlagNT + threadIdx.x;
+    val[r] = p < E ? s.res[slot[r]] : 0u;
+  }
+  unsigned long long bits[kFlagRounds];
+#pragma unroll
+  for (int r = 0; r < kFlagRounds; ++r) {
+    const int64_t p = base + r * kFlagNT + threadIdx.x;
+    bool flag = false;
+    if (p < E) {
+      s.evals[p] = val[r];
+      flag = (val[r] == T + (uint32_t)p);  // first occurrence of a node that is new in this hop
+    }
+    bits[r] = __ballot(flag);
+    if (lane == 0) wcnt[r][wid] = __popcll(bits[r]);
+  }
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < kFlagRounds; ++r) {
+      const int wl = r * (kFlagNT / kWave) + wid;  // word of this workgroup's span; 4 words per block of 256
+      int32_t pre = 0;
+      for (int k = wid & ~3; k < wid; ++k) pre += wcnt[r][k];
+      const int64_t word = (int64_t)bx_ * (kFlagSpan / kWave) + wl;
+      s.fbits[word] = bits[r];
+      s.wpre[word] = (uint16_t)pre;
+      if ((wid & 3) == 3)  // block total, published for the workgroup that will scan
+        __hip_atomic_store(&s.fsum[(int64_t)bx_ * (kFlagSpan / 256) + (wl >> 2)], pre + wcnt[r][wid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = take_ticket_is_last(s.ctr, nwg) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  const int32_t nblk = (E + 255) / 256;
+  const int32_t nnew = scan_block_sums_acquire(s.fsum, nblk, lscan);
   if (threadIdx.x == 0) {
     const int32_t U = st->cnt[h] + nnew;
     st->cnt[h + 1] = U;
@@ -1194,8 +1287,8 @@ struct spp_sampler {
 };
 
 // layout of a slot's first-occurrence rank arrays for `cap` edge positions: [fbits | wpre | fsum] in one allocation
-static inline int64_t rank_words(int64_t cap) { return cap / 64 + 4; }
-static inline int64_t rank_blocks(int64_t cap) { return cap / 256 + 4; }
+static inline int64_t rank_words(int64_t cap) { return cap / 64 + 64 + 4; }
+static inline int64_t rank_blocks(int64_t cap) { return cap / 256 + 16 + 4; }
 static inline size_t rank_off_wpre(int64_t cap) { return (size_t)(8 * rank_words(cap)); }
 static inline size_t rank_off_fsum(int64_t cap) { return (rank_off_wpre(cap) + (size_t)(2 * rank_words(cap)) + 15) & ~(size_t)15; }
 static inline size_t rank_bytes(int64_t cap) { return rank_off_fsum(cap) + (size_t)(4 * rank_blocks(cap)); }
@@ -1665,25 +1758,30 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
   const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
   ga.grid = GG(gseed);
-  hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom);
+  hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom, rowptr,
+                     (int32_t)s->cfg.sizes[0], replace);  // includes hop 0's degree pass
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
     // per-lane row staging of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
-    hipLaunchKernelGGL(k_hop_count, dim3((gt) * gy), dim3(kNT), 0, st, s->d_slots, GG(gt), rowptr, h, f, replace);
+    if (h > 0) hipLaunchKernelGGL(k_hop_count, dim3((gt) * gy), dim3(kNT), 0, st, s->d_slots, GG(gt), rowptr, h, f, replace);
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
         s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(lead.ecap_dyn[h], 0x7fffffff);
-    hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
+    // fast path: k_hop_pick adds up the workgroup sums before its own by itself (a few loads per lane up to
+    // ~2k workgroups per batch); otherwise a single-workgroup scan launch in between
+    const int32_t self_prefix = (!s->generic[h] && gt <= 2048) ? 1 : 0;
+    if (!self_prefix)
+      hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
       if (col32)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, h, f, replace);
+                           col32, h, f, replace, self_prefix, ecap_dev, s->dcap);
       else
         hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, h, f, replace);
+                           col, h, f, replace, self_prefix, ecap_dev, s->dcap);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -1694,7 +1792,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
       hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
-                         GG(gt), col, h, f, replace);
+                         GG(gt), col, h, f, replace, 0, ecap_dev, s->dcap);
       if (col32)
         hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col32,
                            h, f, replace);
@@ -1719,8 +1817,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else
       hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
-    hipLaunchKernelGGL(k_hop_flag, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), h);
-    hipLaunchKernelGGL(k_hop_scan2, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f,
+    const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
+    hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
                        (int32_t)s->tcap[H]);
     if (!s->generic[h]) {
       hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
