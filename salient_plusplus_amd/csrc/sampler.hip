@@ -130,6 +130,12 @@ struct SlotState {
   int32_t pcnt[kPartBuckets];      // ownership buckets of the node list (spp_partition_cfg): [0,P) owners, [P] cache hits
 };
 
+struct __attribute__((aligned(16))) RankWord {
+  unsigned long long bits;
+  uint32_t pre;
+  uint32_t pad;
+};
+
 struct SlotPtrs {
   int32_t* n_ids;
   int32_t* deg;
@@ -139,12 +145,11 @@ struct SlotPtrs {
   uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order)
   uint32_t* res;       // table value of every edge, in bucket order (k_bucket_dedup)
   uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
-  // first occurrences of the hop (new nodes), by edge position: a bitmap, the number of set bits in the
-  // earlier words of the same 256-position block, and the exclusive prefix of the blocks' totals.
-  // rank(q) = fsum[q >> 8] + wpre[q >> 6] + popcount(fbits[q >> 6] below bit q & 63): three reads of arrays
-  // that stay in L2 (E/8 + E/32 + E/64 bytes) replace a 4-byte rank per edge position.
-  unsigned long long* fbits;
-  uint16_t* wpre;
+  // first occurrences of the hop (new nodes), by edge position: per 64 positions one 16-byte record
+  // {bitmap word, set bits in the earlier words of the same 256-position block}, plus the exclusive
+  // prefix of the blocks' totals.  rank(q) = fsum[q >> 8] + fwords[q >> 6].pre + popcount(bits below
+  // q & 63): one 16-byte read (L2) and one of a table small enough for L1 replace a 4-byte rank per edge.
+  RankWord* fwords;
   int32_t* fsum;
   unsigned long long* known;   // [nb][kcap] known nodes per bucket: (node id << 32) | local id (or kPending | pos)
   int32_t* kcount;     // [nb] entries in each known list
@@ -460,10 +465,17 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     if (E > ecap) atomicOr(&s.st->error, kErrEdgeCap);
     if (s.st->dbase[h] + (int64_t)(f > 0 ? f : 0) * S > dcap) atomicOr(&s.st->error, kErrDrawCap);
   }
-  if (i >= T) return;
-  if (self_prefix && (p0 + cnt > ecap || (smp && s.st->dbase[h] + (int64_t)f * (r0 + 1) > dcap))) return;  // see above
-  s.out_rowptr[h][i] = p0;
-  if (s.st->error) return;
+  // lanes without a target (or past a capacity error) stay until the end: the cooperative row reads
+  // below use whole wavefronts
+  bool live = i < T;
+  if (live && self_prefix && (p0 + cnt > ecap || (smp && s.st->dbase[h] + (int64_t)f * (r0 + 1) > dcap))) live = false;
+  if (live) s.out_rowptr[h][i] = p0;
+  if (s.st->error) live = false;
+  if (!live) {
+    cnt = 0;
+    smp = 0;
+    deg = 0;
+  }
   const uint32_t* rng = s.st->rng;
   if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
   if (kGeneric) {
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     }
     return;
   }
-  const int64_t rs = s.rowstart[i];
+  const int64_t rs = live ? s.rowstart[i] : 0;
   const int tid = threadIdx.x;
   if (smp) {
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
@@ -512,18 +524,74 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
     }
   }
-  // neighbour reads in batches of 8 held in registers: the loads of a batch are all issued before the
-  // first use, so a lane has up to 8 independent HBM misses in flight instead of one per iteration
-  for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
-    int32_t nb[8];
+  if constexpr (sizeof(ColT) == 4) {
+    // Cooperative neighbour reads.  One lane fetching its own picks issues `cnt` scattered 4-byte loads:
+    // `cnt` cache-line requests for a row that spans one or two lines, and this kernel is bound by the
+    // number of line requests the memory pipeline keeps in flight, not by bytes.  Instead 8 lanes read
+    // the first 32 neighbours of a row as one contiguous 128-byte request (8 rows per wavefront load
+    // instruction, 8 rounds for the wavefront's 64 rows, all issued before the first use), the rows
+    // pass through a 1 KB LDS stage per wavefront, and each lane takes its picks from there.  Picks at
+    // positions >= 32 (rows of higher degree) are read directly, as before.
+    constexpr int kSeg = 32;
+    typedef int32_t i4 __attribute__((ext_vector_type(4)));
+    typedef int32_t i4u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ i4 stage[kNT / kWave][8][kSeg / 4 + 1];  // +1: rows start in different LDS banks
+    const int lane = tid & (kWave - 1), wid = tid / kWave, j = lane >> 3, part = lane & 7;
+    const int32_t seglen = deg < kSeg ? deg : kSeg;  // 0 for lanes without a target
+    i4 seg[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int32_t k = k0 + u;
-      if (k < cnt) nb[u] = (int32_t)col[rs + (smp ? chosen[k][tid] : k)];
+    for (int r = 0; r < 8; ++r) {
+      const int src = r * 8 + j;
+      const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
+                           (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
+      const int32_t len_r = __shfl(seglen, src, kWave);
+      seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
+    }
+    // far picks (position >= kSeg): direct reads, batched; the neighbour id replaces the position as ~id
+    for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
+      int32_t nb[8];
+      bool far[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int32_t k = k0 + u;
+        const int32_t w = (k < cnt) ? (smp ? chosen[k][tid] : k) : 0;
+        far[u] = k < cnt && w >= kSeg;
+        nb[u] = far[u] ? (int32_t)col[rs + w] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (far[u]) chosen[k0 + u][tid] = ~nb[u];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (k0 + u < cnt) s.cval[p0 + k0 + u] = nb[u];
+    for (int r = 0; r < 8; ++r) {
+      stage[wid][j][part] = seg[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if ((lane >> 3) == r) {
+        const int32_t* row = reinterpret_cast<const int32_t*>(&stage[wid][lane & 7][0]);
+        for (int32_t k = 0; k < cnt; ++k) {
+          const int32_t c = smp ? chosen[k][tid] : k;
+          chosen[k][tid] = c >= 0 ? row[c] : ~c;  // now the neighbour id
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int32_t k = 0; k < cnt; ++k) s.cval[p0 + k] = chosen[k][tid];
+  } else {
+    // neighbour reads in batches of 8 held in registers: the loads of a batch are all issued before the
+    // first use, so a lane has up to 8 independent HBM misses in flight instead of one per iteration
+    for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
+      int32_t nb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int32_t k = k0 + u;
+        if (k < cnt) nb[u] = (int32_t)col[rs + (smp ? chosen[k][tid] : k)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < cnt) s.cval[p0 + k0 + u] = nb[u];
+    }
   }
 }
 
@@ -687,7 +755,8 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
 // when only "first occurrences before q" is wanted)
 __device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
   const uint32_t w = q >> 6;
-  return s.fsum[q >> 8] + (int32_t)s.wpre[w] + __popcll(s.fbits[w] & ((1ull << (q & 63)) - 1ull));
+  const RankWord rw = s.fwords[w];
+  return s.fsum[q >> 8] + (int32_t)rw.pre + __popcll(rw.bits & ((1ull << (q & 63)) - 1ull));
 }
 
 // One workgroup per bucket: known nodes (ids from earlier hops; pending ones of the previous hop are
@@ -892,8 +961,7 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
       int32_t pre = 0;
       for (int k = wid & ~3; k < wid; ++k) pre += wcnt[r][k];
       const int64_t word = (int64_t)bx_ * (kFlagSpan / kWave) + wl;
-      s.fbits[word] = bits[r];
-      s.wpre[word] = (uint16_t)pre;
+      s.fwords[word] = RankWord{bits[r], (uint32_t)pre, 0u};
       if ((wid & 3) == 3)  // block total, published for the workgroup that will scan
         __hip_atomic_store(&s.fsum[(int64_t)bx_ * (kFlagSpan / 256) + (wl >> 2)], pre + wcnt[r][wid], __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -936,8 +1004,8 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
   // 8 edges at a time; each round's loads are all issued before any of them is used
   for (int32_t k0 = 0; k0 < n; k0 += 8) {
     uint32_t v[8], q[8];
-    int32_t c[8], fs[8], wp[8];
-    unsigned long long fb[8];
+    int32_t c[8], fs[8];
+    RankWord rw[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const bool on = k0 + u < n;
@@ -949,15 +1017,14 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
       const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
       q[u] = fresh ? v[u] - (uint32_t)T : 0u;
       fs[u] = fresh ? s.fsum[q[u] >> 8] : 0;
-      wp[u] = fresh ? (int32_t)s.wpre[q[u] >> 6] : 0;
-      fb[u] = fresh ? s.fbits[q[u] >> 6] : 0ull;
+      rw[u] = fresh ? s.fwords[q[u] >> 6] : RankWord{0ull, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (k0 + u >= n) break;
       int32_t id = (int32_t)v[u];
       if (v[u] >= (uint32_t)T) {
-        id = T + fs[u] + wp[u] + __popcll(fb[u] & ((1ull << (q[u] & 63)) - 1ull));
+        id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
         if (q[u] == (uint32_t)(p0 + k0 + u)) s.n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
       }
       a[k0 + u][tid] = id;
@@ -1289,8 +1356,7 @@ struct spp_sampler {
 // layout of a slot's first-occurrence rank arrays for `cap` edge positions: [fbits | wpre | fsum] in one allocation
 static inline int64_t rank_words(int64_t cap) { return cap / 64 + 64 + 4; }
 static inline int64_t rank_blocks(int64_t cap) { return cap / 256 + 16 + 4; }
-static inline size_t rank_off_wpre(int64_t cap) { return (size_t)(8 * rank_words(cap)); }
-static inline size_t rank_off_fsum(int64_t cap) { return (rank_off_wpre(cap) + (size_t)(2 * rank_words(cap)) + 15) & ~(size_t)15; }
+static inline size_t rank_off_fsum(int64_t cap) { return (size_t)(16 * rank_words(cap)); }
 static inline size_t rank_bytes(int64_t cap) { return rank_off_fsum(cap) + (size_t)(4 * rank_blocks(cap)); }
 
 static spp_status dev_alloc(spp_sampler* s, void** out, size_t bytes) {
@@ -1465,11 +1531,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.inv, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * (size_t)etmp);
-      if (e == hipSuccess) e = hipMalloc((void**)&p.fbits, rank_bytes(etmp));
-      if (e == hipSuccess) {
-        p.wpre = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(p.fbits) + rank_off_wpre(etmp));
-        p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p.fbits) + rank_off_fsum(etmp));
-      }
+      if (e == hipSuccess) e = hipMalloc((void**)&p.fwords, rank_bytes(etmp));
+      if (e == hipSuccess) p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p.fwords) + rank_off_fsum(etmp));
       if (e != hipSuccess) {
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
@@ -1490,7 +1553,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       if (!c) {
         c = std::make_shared<Col32>();
         c->device = cfg->device;
-        if (hipMalloc((void**)&c->p, sizeof(int32_t) * (size_t)cfg->nnz) != hipSuccess) {
+        // + slack: k_hop_pick reads rows in 16-byte pieces that may run past the last row's end
+        if (hipMalloc((void**)&c->p, sizeof(int32_t) * ((size_t)cfg->nnz + 16)) != hipSuccess) {
           c->p = nullptr;
           set_error("spp_sampler_create: hipMalloc of the int32 neighbour array failed");
           rc = SPP_ERR_HIP;
@@ -1556,7 +1620,7 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.p.evals) (void)hipFree(sl.p.evals);
     if (sl.p.inv) (void)hipFree(sl.p.inv);
     if (sl.p.res) (void)hipFree(sl.p.res);
-    if (sl.p.fbits) (void)hipFree(sl.p.fbits);
+    if (sl.p.fwords) (void)hipFree(sl.p.fwords);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
   }
   if (s->rng_arena) (void)hipFree(s->rng_arena);
@@ -1593,26 +1657,23 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
   if (need > sl.etmp_cap) {
     int64_t cap = std::max(need, sl.etmp_cap * 2);
     // the rank arrays are preserved: they still describe the previous hop, which k_bucket_dedup needs
-    unsigned long long* old_fbits = sl.p.fbits;
-    uint16_t* old_wpre = sl.p.wpre;
+    RankWord* old_fwords = sl.p.fwords;
     int32_t* old_fsum = sl.p.fsum;
     const int64_t old_cap = sl.etmp_cap;
     (void)hipFree(sl.p.cval); (void)hipFree(sl.p.bpairs); (void)hipFree(sl.p.evals);
     (void)hipFree(sl.p.inv); (void)hipFree(sl.p.res);
-    sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.fbits = nullptr;
+    sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.fwords = nullptr;
     sl.p.inv = nullptr; sl.p.res = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.inv, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMalloc((void**)&sl.p.fbits, rank_bytes(cap)));
-    sl.p.wpre = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(sl.p.fbits) + rank_off_wpre(cap));
-    sl.p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sl.p.fbits) + rank_off_fsum(cap));
-    SPP_HIP_TRY(hipMemcpy(sl.p.fbits, old_fbits, 8 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
-    SPP_HIP_TRY(hipMemcpy(sl.p.wpre, old_wpre, 2 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.fwords, rank_bytes(cap)));
+    sl.p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sl.p.fwords) + rank_off_fsum(cap));
+    SPP_HIP_TRY(hipMemcpy(sl.p.fwords, old_fwords, 16 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
     SPP_HIP_TRY(hipMemcpy(sl.p.fsum, old_fsum, 4 * (size_t)rank_blocks(old_cap), hipMemcpyDeviceToDevice));
-    (void)hipFree(old_fbits);
+    (void)hipFree(old_fwords);
     s->bytes += 24 * (cap - sl.etmp_cap) + (int64_t)rank_bytes(cap) - (int64_t)rank_bytes(sl.etmp_cap);
     sl.etmp_cap = cap;
     changed = true;
