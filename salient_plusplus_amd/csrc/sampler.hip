@@ -433,9 +433,34 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   if ((int64_t)bx_ * kNT >= T && bx_ != 0) return;  // workgroup 0 always runs: it records the totals of an empty hop
   const int32_t i = bx_ * kNT + threadIdx.x;
   int32_t deg = 0, cnt = 0, smp = 0;
+  int64_t rs = 0;
   if (i < T) {
     deg = s.deg[i];
+    rs = s.rowstart[i];
     target_counts(deg, f, replace, cnt, smp);
+  }
+  // Cooperative neighbour reads, issued FIRST: they need only the rows' starts and lengths, not the
+  // picks, so the one long HBM miss of this kernel overlaps the offset sums, the draws and the Floyd steps.
+  // One lane fetching its own picks would issue `cnt` scattered 4-byte loads -- `cnt` cache-line requests
+  // for a row that spans one or two lines.  Instead 8 lanes read the first 32 neighbours of a row as one
+  // contiguous 128-byte request: 8 rows per wavefront load instruction, 8 rounds for the wavefront's 64
+  // rows.  (Rows are read even when a capacity error will discard them: harmless.)
+  constexpr int kSeg = 32;
+  typedef int32_t i4 __attribute__((ext_vector_type(4)));
+  typedef int32_t i4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr bool kCoop = !kGeneric && sizeof(ColT) == 4;
+  i4 seg[kCoop ? 8 : 1];
+  if constexpr (kCoop) {
+    const int lane = threadIdx.x & (kWave - 1), j = lane >> 3, part = lane & 7;
+    const int32_t seglen = deg < kSeg ? deg : kSeg;  // 0 for lanes without a target
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int src = r * 8 + j;
+      const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
+                           (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
+      const int32_t len_r = __shfl(seglen, src, kWave);
+      seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
+    }
   }
   // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
   // workgroup adds up their per-workgroup sums (k_hop_count) itself -- at most a few loads per lane --
@@ -497,7 +522,6 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     }
     return;
   }
-  const int64_t rs = live ? s.rowstart[i] : 0;
   const int tid = threadIdx.x;
   if (smp) {
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
@@ -524,29 +548,11 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
     }
   }
-  if constexpr (sizeof(ColT) == 4) {
-    // Cooperative neighbour reads.  One lane fetching its own picks issues `cnt` scattered 4-byte loads:
-    // `cnt` cache-line requests for a row that spans one or two lines, and this kernel is bound by the
-    // number of line requests the memory pipeline keeps in flight, not by bytes.  Instead 8 lanes read
-    // the first 32 neighbours of a row as one contiguous 128-byte request (8 rows per wavefront load
-    // instruction, 8 rounds for the wavefront's 64 rows, all issued before the first use), the rows
-    // pass through a 1 KB LDS stage per wavefront, and each lane takes its picks from there.  Picks at
-    // positions >= 32 (rows of higher degree) are read directly, as before.
-    constexpr int kSeg = 32;
-    typedef int32_t i4 __attribute__((ext_vector_type(4)));
-    typedef int32_t i4u __attribute__((ext_vector_type(4), aligned(4)));
+  if constexpr (kCoop) {
+    // The rows fetched at the top pass through a 1 KB LDS stage per wavefront, and each lane takes its
+    // picks from there.  Picks at positions >= 32 (rows of higher degree) are read directly.
     __shared__ i4 stage[kNT / kWave][8][kSeg / 4 + 1];  // +1: rows start in different LDS banks
     const int lane = tid & (kWave - 1), wid = tid / kWave, j = lane >> 3, part = lane & 7;
-    const int32_t seglen = deg < kSeg ? deg : kSeg;  // 0 for lanes without a target
-    i4 seg[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int src = r * 8 + j;
-      const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
-                           (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
-      const int32_t len_r = __shfl(seglen, src, kWave);
-      seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
-    }
     // far picks (position >= kSeg): direct reads, batched; the neighbour id replaces the position as ~id
     for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
       int32_t nb[8];

@@ -30,7 +30,10 @@ __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "
            "multilayer_sample", "full_sample", "to_row_major", "serial_index", "NativeComm", "native_comm",
            "set_native_comm"]
 
-_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "16"))
+# four slot-sets of 8 batches (~75 MB of workspace each at fanout [15,10,5], batch 1024): with two, a
+# set's next sampling chain could only start once its previous group was consumed and the consumer
+# waited on chain latency at every group boundary (0.154 -> 0.144 ms per batch on S-papers)
+_MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "32"))
 # distributed Sessions pipeline three stages (sample -> exchange -> consume), one slot-set each plus
 # one in hand: 4 sets of 8
 _MAX_SLOTS_DIST = int(os.environ.get("SPP_MAX_SLOTS_DIST", "32"))
