@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--seed-scheme", default="federated", choices=["federated", "global"],
                     help="N>1: each rank trains on the training vertices of its own partition (the reference "
                          "launcher's default) or on a 1/N slice of one global permutation")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of --steps steps run back to back, pipeline kept full in between; the "
+                         "reported ms_per_step / value are the MEDIAN window's (0 = max(5, ceil(256 / steps)))")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -253,6 +256,32 @@ def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
             "batches_per_s": nb / dt}
 
 
+class device_turn:
+    """Rehearsal mode only (SPP_BENCH_REHEARSAL=1: several ranks share ONE GPU, a development aid).
+    torch's device-wide primitives -- the rocPRIM radix sort / scan behind sort, unique, topk, randperm,
+    cumsum -- stall when several PROCESSES run them concurrently on one device: plain torch.sort hangs
+    with four processes (tools/diag_multiproc_primitives.py, profiles/r02_diag_multiproc_primitives.txt);
+    that, not a kernel of this repository, is what round 1 saw as "all ranks inside torch.unique".
+    The set-up phases that use such primitives (graph construction, cache ranking) therefore take
+    turns under a file lock.  One process per GPU -- every real run -- needs and does nothing here."""
+
+    def __enter__(self):
+        self.f = None
+        if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
+            import fcntl
+            self.f = open("/tmp/spp_bench_rehearsal.lock", "w")
+            fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        if self.f is not None:
+            import fcntl
+            torch.cuda.synchronize()
+            fcntl.flock(self.f, fcntl.LOCK_UN)
+            self.f.close()
+        return False
+
+
 def _trace(msg):
     """progress markers on stderr (SPP_BENCH_TRACE=1): where a multi-rank run stops making progress"""
     if os.environ.get("SPP_BENCH_TRACE") == "1":
@@ -311,15 +340,7 @@ def main():
     nat.require_device()
     _trace("process group up, building the workload")
     t_build = time.perf_counter()
-    if distributed and os.environ.get("SPP_BENCH_REHEARSAL") == "1":
-        # several processes on ONE GPU: torch.unique (single-pass look-back scan) was seen to hang when
-        # four processes ran it concurrently on the same device -- build one rank at a time
-        for r in range(world):
-            if r == rank:
-                wl = make_workload(a.workload, seed=1234, device=dev)
-                torch.cuda.synchronize()
-            dist.barrier()
-    else:
+    with device_turn():
         wl = make_workload(a.workload, seed=1234, device=dev)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
@@ -354,20 +375,28 @@ def main():
         # VIP cache (ddp.py:417-570): the remote vertices most likely to be touched by this rank's
         # mini-batches (analytic model, ddp.py:135-239, on the GPU), alpha * N / P rows fetched from
         # their owners once.  --cache-strategy degree-desc keeps the earlier top-degree proxy.
-        from salient_plusplus_amd.fast_trainer.vip_cache import create_vip_cache, fetch_cache_rows
+        from salient_plusplus_amd.fast_trainer.vip_cache import fetch_cache_rows
         # the vertices this rank's mini-batches start from (ddp.py:33-34 feeds the VIP model with
         # split_idx_parts[rank]['train'])
         vip_seeds = wl.train_idx[(wl.train_idx >= lo) & (wl.train_idx < hi)].contiguous() \
             if a.seed_scheme == "federated" else wl.train_idx
         n_cache = int(a.cache_frac * N / world) if world > 1 else 0
         if n_cache > 0 and a.cache_strategy == "degree-desc":
-            deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
-            deg_remote[lo:hi] = -1
-            cv, cf = fetch_cache_rows(pb, torch.topk(deg_remote, n_cache).indices.sort().values, x_local)
+            with device_turn():
+                deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
+                deg_remote[lo:hi] = -1
+                wanted = torch.topk(deg_remote, n_cache).indices.sort().values
+            cv, cf = fetch_cache_rows(pb, wanted, x_local)
             cache = fs.Cache(rank, world, cv, cf)
         elif n_cache > 0:
-            cache = create_vip_cache(pb, N, x_local, a.cache_frac * 100.0, a.cache_strategy, rowptr=wl.rowptr,
-                                     col=wl.col, train_idx=vip_seeds, fanouts=sizes, batch_size=bs)
+            # create_vip_cache (ddp.py:417-570) in its two halves: the ranking (device-wide sorts: one rank
+            # at a time when the ranks share a GPU) and the collective fetch of the rows from their owners
+            from salient_plusplus_amd.fast_trainer.vip_cache import rank_remote_vertices
+            with device_turn():
+                wanted = rank_remote_vertices(a.cache_strategy, pb, N, int(N / world * a.cache_frac), rowptr=wl.rowptr,
+                                              col=wl.col, train_idx=vip_seeds, fanouts=sizes, batch_size=bs)
+            cv, cf = fetch_cache_rows(pb, wanted, x_local)
+            cache = fs.Cache(rank, world, cv, cf)
             n_cache = int(cache.cached_vertices.numel())
         else:
             cache = fs.Cache()
@@ -376,6 +405,9 @@ def main():
         # issued by the session thread as soon as a group is sampled (most overlap); a training loop with
         # DDP all-reduces keeps the library default (SPP_EXCHANGE_ISSUE=consumer).
         os.environ.setdefault("SPP_EXCHANGE_ISSUE", "thread")
+        # a missing peer / mismatched batch sequence ends in a diagnostic and a non-zero exit well inside the
+        # driver's time limit instead of a kill at the limit (the library default is 300 s)
+        os.environ.setdefault("SPP_EXCHANGE_TIMEOUT_S", "120")
         # collective: every rank joins the RCCL communicator of the native exchange; if any rank cannot,
         # all of them fall back to the torch.distributed transport together
         try:
@@ -419,6 +451,8 @@ def main():
         # feature matrix, so one group of batches through the native exchange can be compared bit for
         # bit with x_full[n_id] (what a single GPU would deliver).  Collective: all ranks run it.
         exchange_verified = None
+        verified_per_rank = None
+        rccl_world = int(L.spp_comm_world(fs.native_comm().handle)) if native else 0
         if native and not a.no_verify:
             import dataclasses
             n_check = min(8, max(1, n_local // bs))
@@ -430,9 +464,11 @@ def main():
             vit.session.quiesce()
             vit.session.close()
             del vit
-            flag = torch.tensor([1 if good else 0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            exchange_verified = bool(int(flag.item()))
+            flags = torch.zeros(world, dtype=torch.int32, device=dev)
+            flags[rank] = 1 if good else 0
+            dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+            verified_per_rank = [bool(v) for v in flags.cpu().tolist()]
+            exchange_verified = all(verified_per_rank)
             _trace(f"exchange verified: {exchange_verified}")
 
         def make_iter(idx):
@@ -464,19 +500,26 @@ def main():
         _trace("barrier passed, timing")
     torch.cuda.synchronize()
     L.spp_profile_enable(1)
-    edges = nodes = 0
+    # R windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides (the
+    # closing bracket of a window is the opening bracket of the next, so the sampler's slots stay full
+    # in between).  A single 20-step window is ~3 ms: its closing synchronize also waits for the refill
+    # chains the sampler has in flight, which makes one short window noisy.  Reported: the median window.
+    R = a.windows if a.windows > 0 else max(5, -(-256 // max(1, a.steps)))
     xb0 = feeder.exchange_bytes()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        b = feeder.next()
-        edges += count_edges(b)
-        nodes += b.x.size(0)
-    torch.cuda.synchronize()
-    if distributed:
-        feeder.quiesce()
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    win = []                                      # (seconds, edges, nodes) per window
+    for _w in range(R):
+        edges = nodes = 0
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            b = feeder.next()
+            edges += count_edges(b)
+            nodes += b.x.size(0)
+        torch.cuda.synchronize()
+        if distributed:
+            feeder.quiesce()
+            dist.barrier()
+        torch.cuda.synchronize()
+        win.append((time.perf_counter() - t0, float(edges), float(nodes)))
     xb1 = feeder.exchange_bytes()
     # gather-kernel time, measured live with HIP events on the launching stream
     ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
@@ -486,13 +529,19 @@ def main():
     nat.check(L.spp_profile_read(prof_kind, C.byref(ms), C.byref(n_launch), C.byref(rows)))
     L.spp_profile_enable(0)
 
-    stats = torch.tensor([dt, float(edges), float(nodes)], dtype=torch.float64, device=dev)
+    stats = torch.tensor(win, dtype=torch.float64, device=dev)      # [R, 3]
     if distributed:
-        tmax = stats[0:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = stats[1:].clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt, edges, nodes = float(tmax[0]), float(tot[0]), float(tot[1])
+        tmax = stats[:, 0].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                  # per window: the slowest rank's time
+        tot = stats[:, 1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)                   # whole-job edges / nodes
+        stats = torch.cat([tmax.unsqueeze(1), tot], dim=1)
+    win = stats.cpu().tolist()
+    order = sorted(range(R), key=lambda k: win[k][0])
+    med = order[R // 2]
+    dt, edges, nodes = win[med]
+    window_ms = [w[0] / a.steps * 1e3 for w in win]
+    timed_total_s = sum(w[0] for w in win)
 
     from salient_plusplus_amd.synthetic import LOCALITY
     locality_note = ""
@@ -517,7 +566,7 @@ def main():
                 "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
-        for pmc_name in ("r01_gather_pmc_papers.json", "r01_gather_pmc.json"):
+        for pmc_name in ("r02_deliver_pmc_papers.json", "r01_gather_pmc_papers.json", "r01_gather_pmc.json"):
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
             if distributed or not os.path.exists(pmc_path):
                 continue
@@ -535,6 +584,10 @@ def main():
             "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
+            "windows": {"n": R, "steps_each": a.steps, "reported": "median window",
+                        "ms_per_step_min": min(window_ms), "ms_per_step_median": window_ms[med],
+                        "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
+                        "ms_per_step_all": [round(v, 5) for v in window_ms]},
             "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
@@ -546,11 +599,15 @@ def main():
             # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
             # by up to the slot-sets in flight, so this is within one group of the bytes of the K batches)
             sent, recv = xb1[0] - xb0[0], xb1[1] - xb0[1]
+            n_timed = a.steps * R
             out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI",
+                               "rccl_world": rccl_world,          # ranks the native communicator really spans
                                "verified_bit_exact_vs_full_table": exchange_verified,
-                               "rank0_sent_MB_per_batch": sent / a.steps / 1e6,
-                               "rank0_received_MB_per_batch": recv / a.steps / 1e6,
-                               "rank0_GBps_out": sent / dt / 1e9, "rank0_GBps_in": recv / dt / 1e9,
+                               "verified_per_rank": verified_per_rank,
+                               "timeout_s": float(os.environ.get("SPP_EXCHANGE_TIMEOUT_S", "300")),
+                               "rank0_sent_MB_per_batch": sent / n_timed / 1e6,
+                               "rank0_received_MB_per_batch": recv / n_timed / 1e6,
+                               "rank0_GBps_out": sent / timed_total_s / 1e9, "rank0_GBps_in": recv / timed_total_s / 1e9,
                                "xgmi_peak_GBps_per_gpu": 7 * 153.0}
         if not a.no_model_step and not distributed:
             try:
