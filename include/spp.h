@@ -411,6 +411,33 @@ spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int64_t* col_de
 spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                  const float* grad_out_dev, int64_t grad_out_stride_elems, int64_t F,
                                  float* grad_x_dev, void* stream);
+/* The fused operand of SAGEConv, [mean_j x_j | x_target] (fp32 [T, 2F], one GEMM with [W_l | W_r] then
+ * replaces lin_l(mean) + lin_r(x_target)): the targets are the first T rows of x (the MFG contract,
+ * driver/models.py:44-45 `x_target = x[:size[1]]`), converted to fp32 in the same pass. */
+spp_status spp_sage_operand_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                    const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
+                                    float* out_dev, int64_t out_stride_elems /* >= 2F */, void* stream);
+/* Its backward: grad_x [S, F] is written completely -- rows < T start from the gradient of the x_target
+ * half, the others from zero, then the mean's gradient is scattered on top (fp32 atomics). */
+spp_status spp_sage_operand_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                     int64_t num_sources, const float* grad_out_dev, int64_t grad_out_stride_elems,
+                                     int64_t F, float* grad_x_dev, void* stream);
+/* The same gradient by GATHER over the transposed hop (built on the fly: count, scan, fill): no fp32
+ * atomics -- 42 M of them per step at papers scale run at the chip's atomic rate.  workspace_dev:
+ * spp_sage_operand_backward_workspace_bytes(T, S, E) bytes of HBM, 16-byte aligned. */
+int64_t spp_sage_operand_backward_workspace_bytes(int64_t num_targets, int64_t num_sources, int64_t num_edges);
+spp_status spp_sage_operand_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                            int64_t num_sources, int64_t num_edges, const float* grad_out_dev,
+                                            int64_t grad_out_stride_elems, int64_t F, float* grad_x_dev,
+                                            void* workspace_dev, int64_t workspace_bytes, void* stream);
+/* x = F.relu(x); x = F.dropout(x, p, training)  (driver/models.py:47-48) in one pass; the keep / drop
+ * decisions come from a counter-based generator keyed by `seed`, and the backward pass needs only y
+ * (y > 0 exactly where the input was positive and kept): grad_x = grad * scale where y > 0, scale = 1/(1-p)
+ * in training and 1 in eval mode. */
+spp_status spp_relu_dropout_forward(const float* x_dev, int64_t n, float p, int32_t training, uint64_t seed,
+                                    float* y_dev, void* stream);
+spp_status spp_relu_dropout_backward(const float* grad_dev, const float* y_dev, int64_t n, float scale,
+                                     float* grad_x_dev, void* stream);
 
 /* GATConv(heads=1) message passing over one MFG hop (driver/models.py:195-231):
  *   e_ij = leaky_relu(a_src[j] + a_dst[i], negative_slope) over row i without its diagonal entry plus

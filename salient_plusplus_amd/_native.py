@@ -109,6 +109,12 @@ SIGNATURES = {
     "spp_vip_frequencies": (C.c_int, [p, p, i64, p, i64, i64, p, i32, p, p, p]),
     "spp_csr_mean_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
     "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, i64, p, p]),
+    "spp_sage_operand_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
+    "spp_sage_operand_backward": (C.c_int, [p, p, i64, i64, p, i64, i64, p, p]),
+    "spp_sage_operand_backward_workspace_bytes": (i64, [i64, i64, i64]),
+    "spp_sage_operand_backward_gather": (C.c_int, [p, p, i64, i64, i64, p, i64, i64, p, p, i64, p]),
+    "spp_relu_dropout_forward": (C.c_int, [p, i64, C.c_float, i32, C.c_uint64, p, p]),
+    "spp_relu_dropout_backward": (C.c_int, [p, p, i64, C.c_float, p, p]),
     "spp_gat_forward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p]),
     "spp_gat_backward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
     "spp_session_try_next": (C.c_int, [p, C.POINTER(BatchDesc)]),

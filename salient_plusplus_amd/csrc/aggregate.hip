@@ -9,6 +9,9 @@
 #include "spp_internal.h"
 
 #include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
 
 namespace spp {
 
@@ -36,7 +39,8 @@ template <typename Tin, bool VEC4>
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
                                                          const Tin* __restrict__ x, int64_t x_stride, int64_t F,
-                                                         int lpr_log2, float* __restrict__ out, int64_t out_stride) {
+                                                         int lpr_log2, float* __restrict__ out, int64_t out_stride,
+                                                         int concat_target) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
@@ -45,6 +49,10 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
   const float inv = 1.0f / (float)(e > b ? e - b : 1);
   if (VEC4) {
     for (int64_t c = (int64_t)lane * 4; c < F; c += (int64_t)lpr * 4) {
+      if (concat_target) {  // [mean | x_target]: the target's own row (targets are the first rows of x), as fp32
+        const f4 own = load4(x + t * x_stride + c);
+        *reinterpret_cast<float4*>(out + t * out_stride + F + c) = make_float4(own.x, own.y, own.z, own.w);
+      }
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       int64_t k = b;
       for (; k + 1 < e; k += 2) {  // two independent rows in flight
@@ -61,6 +69,7 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
     }
   } else {
     for (int64_t c = lane; c < F; c += lpr) {
+      if (concat_target) out[t * out_stride + F + c] = load1(x + t * x_stride + c);
       float acc = 0.f;
       for (int64_t k = b; k < e; ++k) acc += load1(x + col[k] * x_stride + c);
       out[t * out_stride + c] = acc * inv;
@@ -85,6 +94,128 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_bwd(const int64_t* __restri
   }
 }
 
+// grad_x of the fused SAGE operand before the scatter of the mean's gradient: the first T source rows
+// are the targets themselves and start from the gradient of the x_target half, the rest from zero
+// (replaces a zero fill, the zero-padded gradient of the x[:T] slice and the add of the two).
+__global__ __launch_bounds__(kAggNT) void k_grad_init(const float* __restrict__ grad_out, int64_t go_stride, int64_t T,
+                                                      int64_t S, int64_t F, float* __restrict__ grad_x) {
+  const int64_t n4 = S * F / 4;  // F % 4 == 0 (checked by the caller)
+  for (int64_t i = (int64_t)blockIdx.x * kAggNT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kAggNT) {
+    const int64_t srow = (i * 4) / F, c = (i * 4) - srow * F;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (srow < T) v = *reinterpret_cast<const float4*>(grad_out + srow * go_stride + F + c);
+    reinterpret_cast<float4*>(grad_x)[i] = v;
+  }
+}
+
+// ---- ReLU + dropout in one pass (driver/models.py:47-48: x = F.relu(x); x = F.dropout(x, p=0.5)) ----
+// keep / drop from a counter-based generator: element i of the call with `seed` is kept iff
+// hash(seed, i) < (1 - p) * 2^32; the output is relu(x) / (1 - p) where kept, 0 elsewhere.  The backward
+// pass needs no mask: y > 0 exactly where x > 0 and the element was kept.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kAggNT) void k_relu_dropout_fwd(const float* __restrict__ x, int64_t n, uint32_t keep_thr,
+                                                             float scale, uint64_t seed, int training,
+                                                             float* __restrict__ y) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * kAggNT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kAggNT) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o;
+    if (training) {
+      const uint64_t r0 = mix64(seed + 2ull * (uint64_t)i * 0x9E3779B97F4A7C15ull);
+      const uint64_t r1 = mix64(seed + (2ull * (uint64_t)i + 1ull) * 0x9E3779B97F4A7C15ull);
+      o.x = (v.x > 0.f && (uint32_t)r0 < keep_thr) ? v.x * scale : 0.f;
+      o.y = (v.y > 0.f && (uint32_t)(r0 >> 32) < keep_thr) ? v.y * scale : 0.f;
+      o.z = (v.z > 0.f && (uint32_t)r1 < keep_thr) ? v.z * scale : 0.f;
+      o.w = (v.w > 0.f && (uint32_t)(r1 >> 32) < keep_thr) ? v.w * scale : 0.f;
+    } else {
+      o = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+  // tail (n % 4 elements) by the first threads of block 0
+  const int64_t t = n4 * 4 + threadIdx.x;
+  if (blockIdx.x == 0 && t < n) {
+    const float v = x[t];
+    const uint64_t r = mix64(seed + (uint64_t)t * 0xD1B54A32D192ED03ull);
+    y[t] = training ? ((v > 0.f && (uint32_t)r < keep_thr) ? v * scale : 0.f) : fmaxf(v, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(kAggNT) void k_relu_dropout_bwd(const float* __restrict__ g, const float* __restrict__ y,
+                                                             int64_t n, float scale, float* __restrict__ gx) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * kAggNT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kAggNT) {
+    const float4 a = reinterpret_cast<const float4*>(g)[i], b = reinterpret_cast<const float4*>(y)[i];
+    reinterpret_cast<float4*>(gx)[i] = make_float4(b.x > 0.f ? a.x * scale : 0.f, b.y > 0.f ? a.y * scale : 0.f,
+                                                   b.z > 0.f ? a.z * scale : 0.f, b.w > 0.f ? a.w * scale : 0.f);
+  }
+  const int64_t t = n4 * 4 + threadIdx.x;
+  if (blockIdx.x == 0 && t < n) gx[t] = y[t] > 0.f ? g[t] * scale : 0.f;
+}
+
+// ---- backward of the fused operand by GATHER over the transposed hop ----------------------------
+// 42 M fp32 atomics (163 k edges x 256 columns) run at the chip's atomic rate (~325 G/s: 140 us); the
+// transposed adjacency (sources -> targets) costs three small integer passes per step and turns the
+// backward into the same gather-reduce as the forward.
+__global__ __launch_bounds__(kAggNT) void k_tr_count(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                     int64_t T, int32_t* __restrict__ cnt, float* __restrict__ inv) {
+  const int64_t t = (int64_t)blockIdx.x * kAggNT + threadIdx.x;
+  if (t >= T) return;
+  const int64_t b = rowptr[t], e = rowptr[t + 1];
+  inv[t] = 1.0f / (float)(e > b ? e - b : 1);
+  for (int64_t k = b; k < e; ++k) atomicAdd(&cnt[col[k]], 1);
+}
+
+__global__ __launch_bounds__(kAggNT) void k_tr_fill(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                    int64_t T, const int32_t* __restrict__ start,
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ tcol) {
+  const int64_t t = (int64_t)blockIdx.x * kAggNT + threadIdx.x;
+  if (t >= T) return;
+  const int64_t b = rowptr[t], e = rowptr[t + 1];
+  for (int64_t k = b; k < e; ++k) {
+    const int64_t s = col[k];
+    tcol[start[s] + atomicAdd(&cursor[s], 1)] = (int32_t)t;
+  }
+}
+
+// grad_x[s,:] = (s < T ? grad_out[s, F:2F] : 0) + sum over the targets t of s: grad_out[t, :F] / deg(t)
+__global__ __launch_bounds__(kAggNT) void k_operand_bwd_gather(const int32_t* __restrict__ start,
+                                                               const int32_t* __restrict__ tcol,
+                                                               const float* __restrict__ inv, int64_t T, int64_t S,
+                                                               const float* __restrict__ g, int64_t go_stride, int64_t F,
+                                                               int lpr_log2, float* __restrict__ grad_x) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (lpr - 1);
+  const int64_t srow = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
+  if (srow >= S) return;
+  const int32_t b = start[srow], e = start[srow + 1];
+  for (int64_t c = (int64_t)lane * 4; c < F; c += (int64_t)lpr * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (srow < T) acc = *reinterpret_cast<const float4*>(g + srow * go_stride + F + c);
+    int32_t k = b;
+    for (; k + 1 < e; k += 2) {  // two independent rows in flight
+      const int32_t t0 = tcol[k], t1 = tcol[k + 1];
+      const float w0 = inv[t0], w1 = inv[t1];
+      const float4 v0 = *reinterpret_cast<const float4*>(g + (int64_t)t0 * go_stride + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(g + (int64_t)t1 * go_stride + c);
+      acc.x += v0.x * w0 + v1.x * w1; acc.y += v0.y * w0 + v1.y * w1;
+      acc.z += v0.z * w0 + v1.z * w1; acc.w += v0.w * w0 + v1.w * w1;
+    }
+    if (k < e) {
+      const int32_t t0 = tcol[k];
+      const float w0 = inv[t0];
+      const float4 v0 = *reinterpret_cast<const float4*>(g + (int64_t)t0 * go_stride + c);
+      acc.x += v0.x * w0; acc.y += v0.y * w0; acc.z += v0.z * w0; acc.w += v0.w * w0;
+    }
+    *reinterpret_cast<float4*>(grad_x + srow * F + c) = acc;
+  }
+}
+
 static int lanes_log2(int64_t pieces) {
   int l = 0;
   while ((1 << l) < pieces && l < 6) ++l;
@@ -95,9 +226,28 @@ static int lanes_log2(int64_t pieces) {
 
 using namespace spp;
 
+static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                               const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
+                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream);
+
 extern "C" spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                            const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
                                            float* out_dev, int64_t out_stride_elems, void* stream) {
+  return mean_forward(rowptr_dev, col_dev, num_targets, x_dev, x_is_half, x_stride_elems, F, out_dev, out_stride_elems,
+                      0, stream);
+}
+
+extern "C" spp_status spp_sage_operand_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                               const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
+                                               float* out_dev, int64_t out_stride_elems, void* stream) {
+  SPP_REQUIRE(out_stride_elems >= 2 * F, "spp_sage_operand_forward: the operand [mean | x_target] needs 2F columns");
+  return mean_forward(rowptr_dev, col_dev, num_targets, x_dev, x_is_half, x_stride_elems, F, out_dev, out_stride_elems,
+                      1, stream);
+}
+
+static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                               const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
+                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream) {
   SPP_REQUIRE(num_targets >= 0 && F >= 0, "spp_csr_mean_forward: negative size");
   if (num_targets == 0 || F == 0) return SPP_OK;
   SPP_REQUIRE(rowptr_dev && out_dev, "spp_csr_mean_forward: NULL buffer");
@@ -113,7 +263,8 @@ extern "C" spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int6
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
 #define SPP_AGG(TIN, V)                                                                                          \
   hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, \
-                     static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems)
+                     static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems,   \
+                     concat_target)
   if (x_is_half) {
     if (vec) SPP_AGG(__half, true); else SPP_AGG(__half, false);
   } else {
@@ -136,6 +287,111 @@ extern "C" spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
   hipLaunchKernelGGL(k_csr_mean_bwd, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev, num_targets,
                      grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sage_operand_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                int64_t num_sources, const float* grad_out_dev,
+                                                int64_t grad_out_stride_elems, int64_t F, float* grad_x_dev,
+                                                void* stream) {
+  SPP_REQUIRE(num_targets >= 0 && num_sources >= num_targets && F >= 0, "spp_sage_operand_backward: bad sizes");
+  if (num_sources == 0 || F == 0) return SPP_OK;
+  SPP_REQUIRE(grad_x_dev && (grad_out_dev || num_targets == 0), "spp_sage_operand_backward: NULL buffer");
+  SPP_REQUIRE(F % 4 == 0 && grad_out_stride_elems >= 2 * F && grad_out_stride_elems % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(grad_out_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(grad_x_dev) % 16 == 0,
+              "spp_sage_operand_backward: needs F %% 4 == 0 and 16-byte aligned rows");
+  hipStream_t st = as_stream(stream);
+  const int64_t n4 = num_sources * F / 4;
+  const unsigned g0 = (unsigned)std::min<int64_t>(ceil_div(n4, kAggNT), 256 * 32);
+  hipLaunchKernelGGL(k_grad_init, dim3(g0), dim3(kAggNT), 0, st, grad_out_dev, grad_out_stride_elems, num_targets,
+                     num_sources, F, grad_x_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  if (num_targets == 0) return SPP_OK;
+  return spp_csr_mean_backward(rowptr_dev, col_dev, num_targets, grad_out_dev, grad_out_stride_elems, F, grad_x_dev,
+                               stream);
+}
+
+extern "C" int64_t spp_sage_operand_backward_workspace_bytes(int64_t num_targets, int64_t num_sources,
+                                                               int64_t num_edges) {
+  size_t scan_tmp = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                         (int)(num_sources + 1));
+  // cnt/cursor [S+1] | start [S+1] | tcol [E] | inv [T] | scan temporaries   (each 16-byte aligned)
+  auto up = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+  return up(4 * (num_sources + 1)) * 2 + up(4 * num_edges) + up(4 * num_targets) + up((int64_t)scan_tmp) + 64;
+}
+
+extern "C" spp_status spp_sage_operand_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev,
+                                                       int64_t num_targets, int64_t num_sources, int64_t num_edges,
+                                                       const float* grad_out_dev, int64_t grad_out_stride_elems,
+                                                       int64_t F, float* grad_x_dev, void* workspace_dev,
+                                                       int64_t workspace_bytes, void* stream) {
+  SPP_REQUIRE(num_targets >= 0 && num_sources >= num_targets && F >= 0 && num_edges >= 0,
+              "spp_sage_operand_backward_gather: bad sizes");
+  if (num_sources == 0 || F == 0) return SPP_OK;
+  SPP_REQUIRE(num_sources < (1ll << 31) && num_edges < (1ll << 31), "spp_sage_operand_backward_gather: 32-bit indices");
+  SPP_REQUIRE(grad_x_dev && workspace_dev && (grad_out_dev || num_targets == 0),
+              "spp_sage_operand_backward_gather: NULL buffer");
+  SPP_REQUIRE(F % 4 == 0 && grad_out_stride_elems >= 2 * F && grad_out_stride_elems % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(grad_out_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(grad_x_dev) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(workspace_dev) % 16 == 0,
+              "spp_sage_operand_backward_gather: needs F %% 4 == 0 and 16-byte aligned buffers");
+  SPP_REQUIRE(workspace_bytes >= spp_sage_operand_backward_workspace_bytes(num_targets, num_sources, num_edges),
+              "spp_sage_operand_backward_gather: workspace too small");
+  hipStream_t st = as_stream(stream);
+  auto up = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+  char* w = static_cast<char*>(workspace_dev);
+  int32_t* cnt = reinterpret_cast<int32_t*>(w);
+  w += up(4 * (num_sources + 1));
+  int32_t* start = reinterpret_cast<int32_t*>(w);
+  w += up(4 * (num_sources + 1));
+  int32_t* tcol = reinterpret_cast<int32_t*>(w);
+  w += up(4 * num_edges);
+  float* inv = reinterpret_cast<float*>(w);
+  w += up(4 * num_targets);
+  size_t scan_tmp = (size_t)(workspace_bytes - (w - static_cast<char*>(workspace_dev)));
+  SPP_HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(num_sources + 1), st));
+  const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(num_targets, kAggNT));
+  if (num_targets > 0)
+    hipLaunchKernelGGL(k_tr_count, dim3(gt), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, cnt, inv);
+  SPP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w, scan_tmp, cnt, start, (int)(num_sources + 1), st));
+  SPP_HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(num_sources + 1), st));
+  if (num_targets > 0)
+    hipLaunchKernelGGL(k_tr_fill, dim3(gt), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, start, cnt, tcol);
+  const int lpr_log2 = lanes_log2(F / 4);
+  const unsigned grid = (unsigned)ceil_div(num_sources << lpr_log2, kAggNT);
+  hipLaunchKernelGGL(k_operand_bwd_gather, dim3(grid), dim3(kAggNT), 0, st, start, tcol, inv, num_targets, num_sources,
+                     grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_relu_dropout_forward(const float* x_dev, int64_t n, float p, int32_t training, uint64_t seed,
+                                               float* y_dev, void* stream) {
+  SPP_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, "spp_relu_dropout_forward: bad arguments");
+  if (n == 0) return SPP_OK;
+  SPP_REQUIRE(x_dev && y_dev && reinterpret_cast<uintptr_t>(x_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(y_dev) % 16 == 0,
+              "spp_relu_dropout_forward: NULL or unaligned buffer");
+  const double keep = 1.0 - (double)p;
+  const uint32_t thr = keep >= 1.0 ? 0xffffffffu : (uint32_t)(keep * 4294967296.0);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / 4, kAggNT), 256 * 32));
+  hipLaunchKernelGGL(k_relu_dropout_fwd, dim3(grid), dim3(kAggNT), 0, as_stream(stream), x_dev, n, thr,
+                     (float)(1.0 / keep), seed, training, y_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_relu_dropout_backward(const float* grad_dev, const float* y_dev, int64_t n, float scale,
+                                                float* grad_x_dev, void* stream) {
+  SPP_REQUIRE(n >= 0, "spp_relu_dropout_backward: negative size");
+  if (n == 0) return SPP_OK;
+  SPP_REQUIRE(grad_dev && y_dev && grad_x_dev, "spp_relu_dropout_backward: NULL buffer");
+  SPP_REQUIRE((reinterpret_cast<uintptr_t>(grad_dev) | reinterpret_cast<uintptr_t>(y_dev) |
+               reinterpret_cast<uintptr_t>(grad_x_dev)) % 16 == 0, "spp_relu_dropout_backward: unaligned buffer");
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / 4, kAggNT), 256 * 32));
+  hipLaunchKernelGGL(k_relu_dropout_bwd, dim3(grid), dim3(kAggNT), 0, as_stream(stream), grad_dev, y_dev, n, scale,
+                     grad_x_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

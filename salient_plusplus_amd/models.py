@@ -17,51 +17,101 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
 
 
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
 class _MeanAggregate(torch.autograd.Function):
     """out[t] = mean_{e in row t} x[col[e]]  (empty rows give 0, as PyG's mean aggregation).
 
-    With ``x_target`` the result is the fused operand ``[mean | x_target]`` of shape [T, 2F] (fp32): the
-    aggregation writes its half in place, so lin_l and lin_r become ONE GEMM."""
+    With ``concat_target`` the result is the fused operand ``[mean | x_target]`` of shape [T, 2F] (fp32)
+    where x_target = x[:T] (the MFG contract, driver/models.py:44-45): both halves are written by the
+    one kernel, so lin_l and lin_r become ONE GEMM, and the backward writes grad_x completely (target
+    half's gradient, zeros, scattered mean gradient) instead of autograd zero-padding the slice's
+    gradient and adding two full-size tensors."""
 
     @staticmethod
-    def forward(ctx, x, rowptr, col, num_targets, x_target):
+    def forward(ctx, x, rowptr, col, num_targets, concat_target):
         L = nat.load()
         nat.require_device()
         assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float16, torch.float32)
         Fdim = x.size(1)
-        width = 2 * Fdim if x_target is not None else Fdim
+        width = 2 * Fdim if concat_target else Fdim
         out = torch.empty((num_targets, width), dtype=torch.float32, device=x.device)
-        nat.check(L.spp_csr_mean_forward(_p(rowptr), _p(col), num_targets, _p(x), int(x.dtype == torch.float16),
-                                         x.stride(0) if x.size(0) > 1 else Fdim, Fdim, _p(out), width,
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        if x_target is not None:
-            out[:, Fdim:].copy_(x_target)
+        fn = L.spp_sage_operand_forward if concat_target else L.spp_csr_mean_forward
+        nat.check(fn(_p(rowptr), _p(col), num_targets, _p(x), int(x.dtype == torch.float16),
+                     x.stride(0) if x.size(0) > 1 else Fdim, Fdim, _p(out), width, _stream()))
         ctx.save_for_backward(rowptr, col)
         ctx.shape = (x.size(0), Fdim, num_targets, width)
         ctx.in_dtype = x.dtype
-        ctx.fused = x_target is not None
+        ctx.concat = bool(concat_target)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         rowptr, col = ctx.saved_tensors
         S, Fdim, T, width = ctx.shape
-        grad_x = grad_t = None
-        g = grad_out if (grad_out.stride(1) == 1 and grad_out.dtype == torch.float32) else \
-            grad_out.contiguous().to(torch.float32)
+        grad_x = None
         if ctx.needs_input_grad[0]:
-            grad_x = torch.zeros((S, Fdim), dtype=torch.float32, device=g.device)
-            nat.check(nat.load().spp_csr_mean_backward(_p(rowptr), _p(col), T, _p(g), g.stride(0) if T > 1 else width,
-                                                       Fdim, _p(grad_x),
-                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            g = grad_out if (grad_out.stride(1) == 1 and grad_out.dtype == torch.float32) else \
+                grad_out.contiguous().to(torch.float32)
+            L = nat.load()
+            go_stride = g.stride(0) if T > 1 else width
+            if ctx.concat and Fdim % 4 == 0 and go_stride % 4 == 0 and g.data_ptr() % 16 == 0:
+                grad_x = torch.empty((S, Fdim), dtype=torch.float32, device=g.device)
+                E = col.numel()
+                if E * Fdim >= (1 << 22):
+                    # gather over the transposed hop (built here: count, scan, fill) instead of E x F fp32 atomics
+                    nbytes = int(L.spp_sage_operand_backward_workspace_bytes(T, S, E))
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+                    nat.check(L.spp_sage_operand_backward_gather(_p(rowptr), _p(col), T, S, E, _p(g), go_stride, Fdim,
+                                                                 _p(grad_x), _p(ws), nbytes, _stream()))
+                else:
+                    nat.check(L.spp_sage_operand_backward(_p(rowptr), _p(col), T, S, _p(g), go_stride, Fdim,
+                                                          _p(grad_x), _stream()))
+            else:
+                grad_x = torch.zeros((S, Fdim), dtype=torch.float32, device=g.device)
+                nat.check(L.spp_csr_mean_backward(_p(rowptr), _p(col), T, _p(g), go_stride, Fdim, _p(grad_x), _stream()))
+                if ctx.concat:
+                    grad_x[:T] += g[:, Fdim:]
             grad_x = grad_x.to(ctx.in_dtype)
-        if ctx.fused and ctx.needs_input_grad[4]:
-            grad_t = g[:, Fdim:]
-        return grad_x, None, None, None, grad_t
+        return grad_x, None, None, None, None
+
+
+class _ReluDropout(torch.autograd.Function):
+    """F.dropout(F.relu(x), p, training) (driver/models.py:47-48) in one pass over x, with a backward
+    that needs only the output (csrc/aggregate.hip k_relu_dropout_*)."""
+
+    @staticmethod
+    def forward(ctx, x, p, training):
+        L = nat.load()
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        # the seed comes from torch's CPU generator, so torch.manual_seed makes a run repeatable
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF if training else 0
+        nat.check(L.spp_relu_dropout_forward(_p(xc), xc.numel(), float(p), int(bool(training)), seed, _p(y), _stream()))
+        ctx.save_for_backward(y)
+        ctx.scale = 1.0 / (1.0 - float(p)) if training else 1.0
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gc = g.contiguous()
+        gx = torch.empty_like(gc)
+        nat.check(nat.load().spp_relu_dropout_backward(_p(gc), _p(y), gc.numel(), ctx.scale, _p(gx), _stream()))
+        return gx, None, None
+
+
+def relu_dropout(x, p=0.5, training=True):
+    """relu followed by dropout; fp32 CUDA tensors take the fused HIP kernel"""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() > 0 and x.data_ptr() % 16 == 0:
+        return _ReluDropout.apply(x, p, training)
+    return F.dropout(F.relu(x), p=p, training=training)
 
 
 def mean_aggregate(x, rowptr, col, num_targets):
-    return _MeanAggregate.apply(x, rowptr, col, num_targets, None)
+    return _MeanAggregate.apply(x, rowptr, col, num_targets, False)
 
 
 class _TallLinear(torch.autograd.Function):
@@ -117,7 +167,11 @@ class SAGEConv(torch.nn.Module):
         x, x_target = x_pair
         rowptr, col, _ = adj_t.csr()
         # [mean_j x_j | x_target] @ [W_l | W_r]^T: one GEMM instead of two plus an add
-        fused = _MeanAggregate.apply(x, rowptr, col, x_target.size(0), x_target)
+        T = x_target.size(0)
+        if x_target.data_ptr() == x.data_ptr() and x_target.size(1) == x.size(1) and x_target.stride() == x.stride():
+            fused = _MeanAggregate.apply(x, rowptr, col, T, True)           # x_target = x[:T] (the MFG contract)
+        else:                                                               # a foreign target matrix
+            fused = torch.cat([_MeanAggregate.apply(x, rowptr, col, T, False), x_target.to(torch.float32)], dim=1)
         out = _TallLinear.apply(fused, torch.cat([self.lin_l.weight, self.lin_r.weight], dim=1))
         return out if self.lin_l.bias is None else out + self.lin_l.bias
 
@@ -142,13 +196,113 @@ class SAGE(torch.nn.Module):
     def forward(self, x, adjs):
         # the reference converts the whole feature matrix to fp32 first (models.py:43); the first
         # aggregation reads the fp16 rows directly instead (exact) and only the targets are converted
+        if x.is_cuda and _SageStack.usable(self, x, adjs):
+            hops = []
+            for adj_t, _e_id, size in adjs:
+                rowptr, col, _ = adj_t.csr()
+                hops.append((rowptr, col, int(size[1])))
+            weights = [w for conv in self.convs for w in (conv.lin_l.weight, conv.lin_r.weight)]
+            return _SageStack.apply(x, hops, self.training, 0.5, *weights)
         for i, (adj_t, _e_id, size) in enumerate(adjs):
             x_target = x[:size[1]]
             x = self.convs[i]((x, x_target), adj_t)
             if i != self.num_layers - 1:
-                x = F.relu(x)
-                x = F.dropout(x, p=0.5, training=self.training)
+                x = relu_dropout(x, 0.5, self.training)       # F.relu + F.dropout(p=0.5) (models.py:47-48)
         return torch.log_softmax(x, dim=-1)
+
+
+def _wgrad(g, a):
+    """g.T @ a for very tall g [T, N], a [T, K]: batched over row slabs and summed (see _TallLinear)"""
+    T = a.size(0)
+    slabs = min(64, T // 4096)
+    if slabs < 2:
+        return g.t() @ a
+    c = T // slabs
+    out = torch.bmm(g[:slabs * c].view(slabs, c, -1).transpose(1, 2), a[:slabs * c].view(slabs, c, -1)).sum(0)
+    if slabs * c < T:
+        out.addmm_(g[slabs * c:].t(), a[slabs * c:])
+    return out
+
+
+class _SageStack(torch.autograd.Function):
+    """The whole SAGE forward (all layers: fused operand, one GEMM, ReLU + dropout; log_softmax) as ONE
+    autograd node with a hand-written backward.  The kernels are the ones the layer-wise path uses; what
+    goes away is the host side: ~25 autograd nodes, nine Python-level backward calls and the slice /
+    accumulate bookkeeping of x[:T] cost more wall time than the GPU work they enqueue (1.06 ms of
+    kernels in a 1.34 ms step at papers scale)."""
+
+    @staticmethod
+    def usable(model, x, adjs):
+        if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.float16, torch.float32) or x.requires_grad:
+            return False
+        k = x.size(1)
+        for conv in model.convs:
+            if conv.lin_l.bias is not None or conv.lin_l.weight.dtype != torch.float32 or k % 4:
+                return False
+            k = conv.lin_l.weight.size(0)
+        return len(adjs) == len(model.convs)
+
+    @staticmethod
+    def forward(ctx, x, hops, training, p, *weights):
+        L = nat.load()
+        nat.require_device()
+        n_layers = len(hops)
+        st = _stream()
+        h = x
+        operands, acts, wcats = [], [], []
+        for i, (rowptr, col, T) in enumerate(hops):
+            K = h.size(1)
+            A = torch.empty((T, 2 * K), dtype=torch.float32, device=x.device)
+            nat.check(L.spp_sage_operand_forward(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
+                                                 h.stride(0) if h.size(0) > 1 else K, K, _p(A), 2 * K, st))
+            W = torch.cat([weights[2 * i], weights[2 * i + 1]], dim=1)          # [N, 2K] = [W_l | W_r]
+            Z = A @ W.t()
+            operands.append(A)
+            wcats.append(W)
+            if i != n_layers - 1:
+                seed = int(torch.empty((), dtype=torch.int64).random_().item()) if training else 0
+                nat.check(L.spp_relu_dropout_forward(_p(Z), Z.numel(), float(p), int(bool(training)), seed, _p(Z), st))
+                acts.append(Z)                                                  # in place: Z now holds the activation
+                h = Z
+            else:
+                out = torch.log_softmax(Z, dim=-1)
+        ctx.hops = hops
+        ctx.scale = 1.0 / (1.0 - float(p)) if training else 1.0
+        ctx.saved = (operands, acts, wcats, out)
+        ctx.src_rows = [x.size(0)] + [a.size(0) for a in acts]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = nat.load()
+        st = _stream()
+        operands, acts, wcats, out = ctx.saved
+        n_layers = len(ctx.hops)
+        gZ = torch._log_softmax_backward_data(g_out.contiguous(), out, -1, out.dtype)
+        grads = [None] * (2 * n_layers)
+        for i in range(n_layers - 1, -1, -1):
+            A, W = operands[i], wcats[i]
+            K = A.size(1) // 2
+            gW = _wgrad(gZ, A)
+            grads[2 * i], grads[2 * i + 1] = gW[:, :K].contiguous(), gW[:, K:].contiguous()
+            if i == 0:
+                break
+            rowptr, col, T = ctx.hops[i]
+            S = ctx.src_rows[i]
+            gA = gZ @ W                                                         # [T, 2K]
+            gH = torch.empty((S, K), dtype=torch.float32, device=gA.device)
+            E = col.numel()
+            if E * K >= (1 << 22):
+                nbytes = int(L.spp_sage_operand_backward_workspace_bytes(T, S, E))
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=gA.device)
+                nat.check(L.spp_sage_operand_backward_gather(_p(rowptr), _p(col), T, S, E, _p(gA), 2 * K, K, _p(gH),
+                                                             _p(ws), nbytes, st))
+            else:
+                nat.check(L.spp_sage_operand_backward(_p(rowptr), _p(col), T, S, _p(gA), 2 * K, K, _p(gH), st))
+            nat.check(L.spp_relu_dropout_backward(_p(gH), _p(acts[i - 1]), gH.numel(), ctx.scale, _p(gH), st))
+            gZ = gH
+        ctx.saved = None
+        return (None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------------
@@ -245,6 +399,5 @@ class GAT(torch.nn.Module):
             x_target = x[:size[1]]
             x = self.convs[i]((x, x_target), adj_t)
             if i != self.num_layers - 1:
-                x = F.relu(x)
-                x = F.dropout(x, p=0.5, training=self.training)
+                x = relu_dropout(x, 0.5, self.training)
         return torch.log_softmax(x, dim=-1)

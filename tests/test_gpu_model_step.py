@@ -217,3 +217,51 @@ def test_gat_model_runs_and_learns_shapes():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.7 * losses[0]
+
+
+@pytest.mark.parametrize("T,S,F,maxdeg,dtype", [
+    (300, 900, 64, 12, torch.float32),        # small hop: backward by fp32 atomics
+    (6000, 40000, 256, 40, torch.float32),    # E * F >= 2^22: backward by gather over the transposed hop
+    (5000, 30000, 128, 30, torch.float16),    # the first layer's shape: fp16 rows in, no input gradient
+])
+def test_sage_operand_forward_backward(T, S, F, maxdeg, dtype):
+    """[mean_j x_j | x[:T]] in one kernel and its backward (both formulations) against plain torch."""
+    from salient_plusplus_amd.models import _MeanAggregate
+    rowptr, col = _random_hop(T, S, maxdeg, T + F)
+    x = torch.randn((S, F), generator=torch.Generator().manual_seed(3)).to(dtype).cuda()
+    got = _MeanAggregate.apply(x, rowptr, col, T, True)
+    want = torch.cat([_ref_mean(x, rowptr, col, T), x[:T].float()], dim=1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    if dtype == torch.float32:
+        xg = x.clone().requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        w = torch.randn((T, 2 * F), device="cuda")
+        (_MeanAggregate.apply(xg, rowptr, col, T, True) * w).sum().backward()
+        (torch.cat([_ref_mean(xr, rowptr, col, T), xr[:T]], dim=1) * w).sum().backward()
+        torch.testing.assert_close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_relu_dropout_fused():
+    """relu + dropout in one pass: eval mode = relu exactly; training: every output is 0 or 2*relu(x),
+    about half of the positive inputs survive, the backward is grad * 2 exactly where the output is
+    positive, and torch.manual_seed makes the mask repeatable."""
+    from salient_plusplus_amd.models import relu_dropout
+    x = torch.randn((4099, 257), device="cuda")          # odd sizes: the scalar tail is exercised
+    torch.testing.assert_close(relu_dropout(x, 0.5, False), torch.relu(x), rtol=0, atol=0)
+    torch.manual_seed(7)
+    xg = x.clone().requires_grad_(True)
+    y = relu_dropout(xg, 0.5, True)
+    pos = x > 0
+    assert bool(((y == 0) | (y == 2 * torch.relu(x))).all())
+    assert not bool((y[~pos] != 0).any())
+    kept = float((y[pos] > 0).float().mean())
+    assert 0.49 < kept < 0.51, kept
+    g = torch.randn_like(x)
+    y.backward(g)
+    torch.testing.assert_close(xg.grad, torch.where(y > 0, 2 * g, torch.zeros_like(g)), rtol=0, atol=0)
+    torch.manual_seed(7)
+    assert torch.equal(relu_dropout(x, 0.5, True), y.detach())
+    torch.manual_seed(8)
+    assert not torch.equal(relu_dropout(x, 0.5, True), y.detach())
+    kept25 = float((relu_dropout(x, 0.75, True)[pos] > 0).float().mean())
+    assert 0.24 < kept25 < 0.26, kept25
