@@ -36,7 +36,7 @@ TORCH_DIR=$($PY -c "import torch, os; print(os.path.dirname(torch.__file__))")
 PYINC=$($PY -c "import sysconfig; print(sysconfig.get_paths()['include'])")
 ABI=$($PY -c "import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")
 CXX="$LLVM/bin/clang++"
-FLAGS=(-O3 -march=native -std=c++17 -fPIC -fopenmp -DAT_PARALLEL_OPENMP -DNDEBUG
+FLAGS=(-O3 -march=x86-64-v3 -std=c++17 -fPIC -fopenmp -DAT_PARALLEL_OPENMP -DNDEBUG
        -DTORCH_EXTENSION_NAME=fast_sampler -DTORCH_API_INCLUDE_EXTENSION_H
        -D_GLIBCXX_USE_CXX11_ABI=$ABI -w
        -I"$REF" -I"$REF/parallel-hashmap"

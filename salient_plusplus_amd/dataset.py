@@ -41,6 +41,67 @@ def csr_permute_symmetric(rowptr: torch.Tensor, col: torch.Tensor, invperm: torc
     return new_rowptr, new_col
 
 
+class _VertexOrder(NamedTuple):
+    """A relabelling of the vertices: ``old_id[new]`` and ``new_id[old]`` (inverse permutations) and the
+    first new id of every partition (``part_offsets``, P + 1 entries); all on one device."""
+    old_id: torch.Tensor
+    new_id: torch.Tensor
+    part_offsets: torch.Tensor
+    num_parts: int
+
+
+def _vertex_order(partition_labels: torch.Tensor, probability_of_access: Optional[torch.Tensor], device) -> _VertexOrder:
+    """Partitions in ascending order; inside a partition descending access probability, ties by old id.
+    Two stable sorts (minor key first) instead of the reference's single float key
+    ``2 * (P - 1 - label) + probability`` (dataset.py:309-320): the same order for probabilities in
+    [0, 1], exact for any number of partitions, and reproducible when probabilities tie."""
+    labels = partition_labels.to(device=device, dtype=torch.int64)
+    n = labels.numel()
+    P = int(labels.max()) + 1 if n else 0
+    if probability_of_access is None:
+        hot_first = torch.arange(n, device=device)
+    else:
+        prob = probability_of_access.to(device)
+        if prob.dim() == 2:                                  # [P, N]: row p is valid for partition p's vertices
+            prob = prob.gather(0, labels.unsqueeze(0)).squeeze(0)
+        elif prob.dim() != 1:
+            raise ValueError(f"probability_of_access must be 1-D or 2-D, got {prob.dim()}-D")
+        hot_first = torch.sort(prob, descending=True, stable=True).indices
+    by_part = torch.sort(labels[hot_first], stable=True).indices
+    old_id = hot_first[by_part]
+    new_id = torch.empty_like(old_id)
+    new_id[old_id] = torch.arange(n, device=device)
+    offsets = torch.zeros(P + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(torch.bincount(labels, minlength=P), 0)
+    return _VertexOrder(old_id, new_id, offsets, P)
+
+
+def _bucket_splits(split_idx: Mapping[str, torch.Tensor], order: _VertexOrder):
+    """{partition: {split: new ids of the split's vertices owned by the partition}} (dataset.py:327-343).
+    A partition owns a contiguous range of new ids, so the owner is a search in ``part_offsets``."""
+    dev = order.new_id.device
+    out = {r: dict() for r in range(order.num_parts)}
+    for name, ids in split_idx.items():
+        relabelled = order.new_id[ids.to(dev)]
+        owner = torch.searchsorted(order.part_offsets, relabelled, right=True) - 1
+        grouped = relabelled[torch.sort(owner, stable=True).indices].cpu()
+        cuts = torch.cumsum(torch.bincount(owner, minlength=order.num_parts), 0).tolist()
+        lo = 0
+        for r, hi in enumerate(cuts):
+            out[r][name] = grouped[lo:hi].clone()
+            lo = hi
+    return out
+
+
+def _take_rows(t: torch.Tensor, rows: torch.Tensor, device) -> torch.Tensor:
+    """t[rows] on `device`; 2-D tables go through the HIP row gather (spp_gather_rows) when that is a GPU"""
+    device = torch.device(device)
+    if device.type == "cuda" and t.dim() == 2 and t.stride(-1) == 1:
+        from . import fast_sampler as fs
+        return fs.serial_index(t.to(device), rows.to(device))
+    return t.to(device)[rows.to(device)]
+
+
 class FastDataset(NamedTuple):
     name: str
     x: torch.Tensor
@@ -149,58 +210,44 @@ class DisjointPartFeatReorderedDataset(NamedTuple):
     @classmethod
     def reorder_and_save(cls, dataset: FastDataset, partition_labels: torch.Tensor,
                          probability_of_access: Optional[torch.Tensor], dir: Path, device=None):
-        """dataset.py:270-369.  The heavy steps (CSR relabel + sort, feature permutation) run on
-        `device` (default: the GPU when there is one).  Returns the directory written."""
+        """Write the partitioned, vertex-reordered form of `dataset` under
+        ``dir/metis-reordered-k<P>/<name>/`` (what driver/dataset.py:270-369 produces) and return that
+        directory.  New vertex ids: partition by partition, inside a partition by descending access
+        probability (1-D: one value per vertex; 2-D [P, N]: row p applies to the vertices of partition p).
+
+        Everything proportional to the graph runs on `device` (default: the current GPU): the vertex
+        order, the symmetric CSR relabel + coalesce, the split relabel/bucketing, and the feature rows,
+        which are gathered and written ONE PARTITION AT A TIME (the reordered feature matrix of a
+        papers-scale dataset is never materialised as a whole)."""
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
-        partition_labels = partition_labels.to(torch.int64)
-        num_parts = int(partition_labels.max()) + 1
-        sizes_partition = torch.bincount(partition_labels, minlength=num_parts)
-        # ascending partition id globally, descending access probability inside a partition (:299-320)
-        ordering_vals = 2 * (partition_labels.max() - partition_labels.float())
-        if probability_of_access is not None:
-            if probability_of_access.dim() == 1:
-                ordering_vals += probability_of_access.to(ordering_vals.device)
-            elif probability_of_access.dim() == 2:
-                for part in range(probability_of_access.size(0)):
-                    mask = partition_labels == part
-                    ordering_vals[mask] += probability_of_access[part][mask].to(ordering_vals.dtype)
-            else:
-                print(f"*WARNING* Unexpected dimensionality of probability_of_access ({probability_of_access.dim()})")
-        perm = ordering_vals.argsort(descending=True, stable=True)      # stable: reproducible ties
-        invperm = perm.argsort()
+        device = torch.device(device)
+        order = _vertex_order(partition_labels, probability_of_access, device)
+        P = order.num_parts
+        target = Path(dir) / f"metis-reordered-k{P}" / dataset.name
+        target.mkdir(parents=True, exist_ok=False)
 
-        rowptr_p, col_p = csr_permute_symmetric(dataset.rowptr.to(device), dataset.col.to(device), invperm)
-        rowptr_p, col_p = rowptr_p.cpu(), col_p.cpu()
-
-        split_idx_p = dict()                                            # saved empty, as the reference does (:326)
-        split_idx_parts = {r: dict() for r in range(num_parts)}
-        for k, v in dataset.split_idx.items():
-            partition_ids = partition_labels[v]
-            local_part_size = torch.bincount(partition_ids, minlength=num_parts)
-            local_part_offset = torch.cat((torch.tensor([0]), torch.cumsum(local_part_size, 0)))
-            sorted_relabeled = invperm[v][partition_ids.argsort(stable=True)]
-            for r in range(num_parts):
-                split_idx_parts[r][k] = sorted_relabeled[local_part_offset[r]:local_part_offset[r + 1]]
-
-        x_p = dataset.x[perm]
-        y_p = dataset.y[perm]
-        part_offsets_p = torch.cat((torch.tensor([0]), torch.cumsum(sizes_partition, 0)))
-
-        prefix = Path(dir) / f"metis-reordered-k{num_parts}" / dataset.name
-        prefix.mkdir(parents=True, exist_ok=False)
-        torch.save(num_parts, prefix / "num_parts.pt")
-        torch.save(rowptr_p, prefix / "rowptr.pt")
-        torch.save(col_p, prefix / "col.pt")
-        torch.save(split_idx_p, prefix / "split_idx.pt")
-        torch.save(split_idx_parts, prefix / "split_idx_parts.pt")
-        torch.save(part_offsets_p, prefix / "part_offsets.pt")
-        torch.save(y_p, prefix / "y.pt")
-        torch.save(dict(dataset.meta_info), prefix / "meta_info.pt")
-        torch.save(dataset.name, prefix / "name.pt")
-        for r in range(num_parts):
-            torch.save(x_p[part_offsets_p[r]:part_offsets_p[r + 1]].to(torch.float16).clone(), prefix / f"x{r}.pt")
-        return prefix
+        rowptr_new, col_new = csr_permute_symmetric(dataset.rowptr.to(device), dataset.col.to(device), order.new_id)
+        files = {
+            "num_parts": P,
+            "rowptr": rowptr_new.cpu(),
+            "col": col_new.cpu(),
+            "split_idx": dict(),                                   # the reference leaves it empty (:326)
+            "split_idx_parts": _bucket_splits(dataset.split_idx, order),
+            "part_offsets": order.part_offsets.cpu(),
+            "y": _take_rows(dataset.y, order.old_id, device).cpu(),
+            "meta_info": dict(dataset.meta_info),
+            "name": dataset.name,
+        }
+        del rowptr_new, col_new
+        for stem, value in files.items():
+            torch.save(value, target / f"{stem}.pt")
+        bounds = files["part_offsets"].tolist()
+        x_src = dataset.x.to(device)                               # uploaded once; gathered partition by partition
+        for r in range(P):
+            rows = _take_rows(x_src, order.old_id[bounds[r]:bounds[r + 1]], device)
+            torch.save(rows.to(torch.float16).cpu(), target / f"x{r}.pt")
+        return target
 
     def get_RangePartitionBook(self):
         return RangePartitionBook(self.rank, self.num_parts, self.part_offsets)

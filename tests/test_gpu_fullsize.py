@@ -59,9 +59,11 @@ def test_fullsize_batches_bit_exact_vs_oracle(products):
 
 def test_fullsize_epoch_properties(products):
     """Size-independent invariants on every batch of a 48-batch run."""
+    _epoch_properties(products, 48)
+
+
+def _epoch_properties(wl, nb):
     from salient_plusplus_amd import fast_sampler as fs
-    wl = products
-    nb = 48
     idx = wl.train_idx[:nb * wl.batch_size].contiguous()
     deg = (wl.rowptr[1:] - wl.rowptr[:-1])
     fan = wl.fanouts
@@ -75,6 +77,10 @@ def test_fullsize_epoch_properties(products):
             x, y, adjs, (start, stop) = b
             U = x.size(0)
             assert stop - start == wl.batch_size and y.shape == (wl.batch_size, 1)
+            # the targets of the innermost hop are the seeds, and they are the first rows of the batch
+            seeds = idx[start:stop]
+            assert torch.equal(y.view(-1), wl.y[seeds])
+            assert torch.equal(x[:stop - start], wl.x[seeds])
             # hops are outermost first; target nodes are a prefix of the source nodes
             T_prev = None
             for k, (rp, cl, e_id, (T, S)) in enumerate(adjs):
@@ -100,3 +106,64 @@ def test_fullsize_epoch_properties(products):
         s.close()
     assert seen == nb
     del deg
+
+
+# ---- the other single-GPU workloads BASELINE.json names -------------------------------------------
+@pytest.fixture(scope="module")
+def arxiv():
+    from salient_plusplus_amd import _native as nat
+    nat.load()
+    nat.require_device()
+    from salient_plusplus_amd.synthetic import make_workload
+    wl = make_workload("S-arxiv", seed=1234, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    return wl
+
+
+def test_arxiv_batches_bit_exact_vs_oracle_and_epoch_properties(arxiv):
+    """configs[0]'s graph (S-arxiv: 169 k nodes, F=128, batch 1024, fanout [15,10,5]): two batches
+    against the oracle bit for bit, then every batch of an epoch slice through the invariants."""
+    from oracle import oracle as orc
+    wl = arxiv
+    nb = 12
+    idx = wl.train_idx[:nb * wl.batch_size].contiguous()
+    rowptr, col, idx_h = wl.rowptr.cpu().numpy(), wl.col.cpu().numpy(), idx.cpu().numpy()
+    x_h, y_h = wl.x.cpu().numpy(), wl.y.cpu().numpy()
+    ranges = orc.batch_ranges(idx.numel(), wl.batch_size, False, True, nb)
+    for b, batch in enumerate(iter(_sampler(wl, idx))):
+        start, stop = int(ranges[b][0]), int(ranges[b][1])
+        assert (batch.idx_range.start, batch.idx_range.stop) == (start, stop)
+        if b not in (0, 9):
+            continue
+        m = orc.sample_batch(rowptr, col, idx_h, start, stop, wl.fanouts)
+        for adj, hop in zip(batch.adjs, m.hops):
+            rp, cl, _ = adj.adj_t.csr()
+            np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
+            np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+        np.testing.assert_array_equal(batch.x.cpu().numpy().view(np.uint16), x_h[m.n_id].view(np.uint16))
+        np.testing.assert_array_equal(batch.y.cpu().numpy(), y_h[m.n_id[:stop - start]])
+    _epoch_properties(wl, nb)
+
+
+def test_mag_fullsize_epoch_properties():
+    """configs[4] at FULL size on one GPU (S-mag: 121.7 M nodes, 2.6 G nnz, F=768 fp16 = 187 GB of features,
+    fanout [25,15]): every batch of a 24-batch run through the size-independent invariants (the oracle
+    would need the 21 GB topology on the host; fixture-size parity for this fanout is in
+    tests/golden/mfg_a_s25_15.npz).  Needs an otherwise empty MI355X."""
+    from salient_plusplus_amd import fast_sampler as fs0
+    fs0.clear_resident_cache()                                   # HBM copies / pooled samplers of earlier tests
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 250 * (1 << 30):
+        pytest.skip(f"S-mag needs ~235 GB of HBM, {free / (1 << 30):.0f} GB are free")
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.synthetic import make_workload
+    wl = make_workload("S-mag", seed=1234, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    try:
+        assert wl.x.shape == (121_751_666, 768) and wl.fanouts == [25, 15]
+        _epoch_properties(wl, 24)
+    finally:
+        del wl
+        fs.clear_resident_cache()
+        torch.cuda.empty_cache()
