@@ -889,25 +889,27 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // first-occurrence ranking
 // ----------------------------------------------------------------------------------------------
-// scan_block_sums for sums that other workgroups of the SAME launch stored with agent-scope stores
+constexpr int kFlagNT = kNT;                    // 256 threads: a 1024-thread workgroup needs 16 free wave slots on ONE CU at
+                                                // once and waited for them behind the delivery kernel (36 us per batch in situ, 12 alone)
+constexpr int kFlagRounds = 4;                  // positions per thread; one round = one 256-position block = 4 bitmap words
+constexpr int kFlagSpan = kFlagNT * kFlagRounds;  // positions per workgroup (one ticket each)
+static_assert(kFlagNT == 256, "a round of the workgroup is one rank block");
+
+// scan_block_sums for sums that other workgroups of the SAME launch stored with agent-scope stores,
+// by a kFlagNT-thread workgroup
 __device__ int32_t scan_block_sums_acquire(int32_t* a, int32_t n, int32_t* lds) {
   int32_t carry = 0;
-  for (int32_t base = 0; base < n; base += kScanNT) {
+  for (int32_t base = 0; base < n; base += kFlagNT) {
     const int32_t i = base + threadIdx.x;
     const int32_t v = (i < n) ? acquire_i32(&a[i]) : 0;
     int32_t tot;
-    const int32_t ex = block_exclusive_scan<int32_t, kScanNT>(v, lds, &tot);
+    const int32_t ex = block_exclusive_scan<int32_t, kFlagNT>(v, lds, &tot);
     if (i < n) a[i] = carry + ex;
     carry += tot;
     __syncthreads();
   }
   return carry;
 }
-
-constexpr int kFlagNT = 1024;                   // workgroup of k_hop_flag
-constexpr int kFlagRounds = 4;                  // positions per thread
-constexpr int kFlagSpan = kFlagNT * kFlagRounds;  // positions per workgroup = 64 bitmap words = 16 blocks of 256
-static_assert(kFlagNT == kScanNT, "the last workgroup scans with its own threads");
 
 // Per edge position p: the table value of its node back in position order (reads of res through inv:
 // a 4-byte random READ of a just-written array is served by L2 / Infinity Cache, a 4-byte random
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
                                                        int32_t f, int32_t ucap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t wcnt[kFlagRounds][kFlagNT / kWave];
-  __shared__ int32_t lscan[kScanNT / kWave + 1];
+  __shared__ int32_t lscan[kFlagNT / kWave + 1];
   __shared__ int is_last;
   const SlotPtrs& s = slots[gg.first_slot + by_];
   SlotState* st = s.st;
@@ -962,15 +964,13 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
   __syncthreads();
   if (lane == 0) {
 #pragma unroll
-    for (int r = 0; r < kFlagRounds; ++r) {
-      const int wl = r * (kFlagNT / kWave) + wid;  // word of this workgroup's span; 4 words per block of 256
+    for (int r = 0; r < kFlagRounds; ++r) {  // round r = rank block r of this workgroup, wave wid = its word wid
       int32_t pre = 0;
-      for (int k = wid & ~3; k < wid; ++k) pre += wcnt[r][k];
-      const int64_t word = (int64_t)bx_ * (kFlagSpan / kWave) + wl;
-      s.fwords[word] = RankWord{bits[r], (uint32_t)pre, 0u};
-      if ((wid & 3) == 3)  // block total, published for the workgroup that will scan
-        __hip_atomic_store(&s.fsum[(int64_t)bx_ * (kFlagSpan / 256) + (wl >> 2)], pre + wcnt[r][wid], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < wid; ++k) pre += wcnt[r][k];
+      const int64_t blk = (int64_t)bx_ * kFlagRounds + r;
+      s.fwords[blk * (kFlagNT / kWave) + wid] = RankWord{bits[r], (uint32_t)pre, 0u};
+      if (wid == kFlagNT / kWave - 1)  // block total, published for the workgroup that will scan
+        __hip_atomic_store(&s.fsum[blk], pre + wcnt[r][wid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores before the barrier
