@@ -29,6 +29,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# As the reference's launcher does (utils/exp_driver.py:154 exports OMP_NUM_THREADS=1).  On the GPU boxes
+# nproc is 256 while the cgroup grants 16 cores: torch's intra-op OpenMP pool then spins 256 threads after
+# every small CPU op of an epoch boundary (the seeded CPU randperm of the shuffler), exhausts the CPU quota
+# and the whole process is throttled for the rest of the 100 ms period -- a 75 ms stall with an idle GPU
+# every few epochs (tools/epoch_boundary.py: 9 of 24 S-arxiv epochs took 80 ms instead of 7).
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -1312,6 +1312,7 @@ static std::map<std::tuple<const void*, int64_t, int>, std::weak_ptr<Col32>> g_c
 struct SlotHost {
   SlotPtrs p{};
   hipEvent_t done = nullptr;        // own event object
+  hipEvent_t exported = nullptr;    // recorded by the consumer after its copies out of this slot (session.hip)
   hipEvent_t wait_on = nullptr;     // event that marks this slot's batch complete (group leader's)
   SlotState* host_state = nullptr;  // into the pinned mirror array
   bool sampled = false;
@@ -1339,6 +1340,7 @@ struct spp_sampler {
   // creation order; creating them once, back to back, keeps the delivery stream and the sampling
   // streams on distinct queues for the whole run instead of re-rolling the mapping every epoch).
   hipStream_t deliver_stream = nullptr;
+  hipStream_t comm_stream = nullptr;   // native exchange (created on first use)
   hipStream_t work_streams[kMaxWorkStreams] = {};
   SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
   SlotState* d_states = nullptr;     // contiguous device states
@@ -1354,6 +1356,8 @@ struct spp_sampler {
   uint32_t* rng_arena_seeds_dev = nullptr;
   int64_t rng_arena_seeds_cap = 0;
   hipEvent_t rng_arena_ready = nullptr;
+  hipEvent_t inputs_ready = nullptr;  // sampler_inputs_event
+  std::unique_ptr<Worker> workers[2];  // persistent host threads lent to Sessions (sampler_worker)
   bool xcd_affinity = true;          // GroupGrid.interleave of the grouped launches (SPP_XCD_AFFINITY=0: batch-major ids)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
   XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
@@ -1545,7 +1549,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       }
       s->bytes += 24 * etmp + (int64_t)rank_bytes(etmp);
     }
-    if (rc == SPP_OK && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+    if (rc == SPP_OK && (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&sl.exported, hipEventDisableTiming) != hipSuccess)) {
       set_error("spp_sampler_create: hipEventCreate failed");
       rc = SPP_ERR_HIP;
     }
@@ -1617,10 +1622,13 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
 
 extern "C" void spp_sampler_destroy(spp_sampler* s) {
   if (!s) return;
+  s->workers[0].reset();  // joins the host threads before anything they might touch goes away
+  s->workers[1].reset();
   (void)hipSetDevice(s->cfg.device);
   (void)hipDeviceSynchronize();
   for (auto& sl : s->slots) {
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.exported) (void)hipEventDestroy(sl.exported);
     if (sl.p.cval) (void)hipFree(sl.p.cval);
     if (sl.p.bpairs) (void)hipFree(sl.p.bpairs);
     if (sl.p.evals) (void)hipFree(sl.p.evals);
@@ -1632,11 +1640,17 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   if (s->rng_arena) (void)hipFree(s->rng_arena);
   if (s->rng_arena_seeds_dev) (void)hipFree(s->rng_arena_seeds_dev);
   if (s->rng_arena_ready) (void)hipEventDestroy(s->rng_arena_ready);
+  if (s->inputs_ready) (void)hipEventDestroy(s->inputs_ready);
   if (s->h_states) (void)hipHostFree(s->h_states);
   if (s->deliver_stream) (void)hipStreamDestroy(s->deliver_stream);
   for (auto st : s->work_streams)
     if (st) (void)hipStreamDestroy(st);
+  if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
   for (auto& xb : s->xbuf) {
+    if (xb.cnt_dev) (void)hipFree(xb.cnt_dev);
+    if (xb.cnt_host) (void)hipHostFree(xb.cnt_host);
+    if (xb.cnt_ready) (void)hipEventDestroy(xb.cnt_ready);
+    if (xb.rows_done) (void)hipEventDestroy(xb.rows_done);
     if (xb.send_ids) (void)hipFree(xb.send_ids);
     if (xb.recv_ids) (void)hipFree(xb.recv_ids);
     if (xb.send_rows) (void)hipFree(xb.send_rows);
@@ -2070,6 +2084,44 @@ spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t n
   *cap = ncap;
   s->bytes += (ncap) * unit_bytes;
   return SPP_OK;
+}
+
+Worker* sampler_worker(spp_sampler* s, int which) {
+  if (!s->workers[which]) s->workers[which].reset(new Worker());
+  return s->workers[which].get();
+}
+
+spp_status sampler_xbuf_counts(spp_sampler* s, XBuf* xb, int64_t bytes) {
+  (void)s;
+  if (bytes > xb->cnt_bytes) {
+    if (xb->cnt_dev) (void)hipFree(xb->cnt_dev);
+    if (xb->cnt_host) (void)hipHostFree(xb->cnt_host);
+    xb->cnt_dev = nullptr;
+    xb->cnt_host = nullptr;
+    xb->cnt_bytes = 0;
+    SPP_HIP_TRY(hipMalloc((void**)&xb->cnt_dev, (size_t)bytes));
+    SPP_HIP_TRY(hipHostMalloc((void**)&xb->cnt_host, (size_t)bytes, hipHostMallocDefault));
+    xb->cnt_bytes = bytes;
+  }
+  if (!xb->cnt_ready) SPP_HIP_TRY(hipEventCreateWithFlags(&xb->cnt_ready, hipEventDisableTiming));
+  if (!xb->rows_done) SPP_HIP_TRY(hipEventCreateWithFlags(&xb->rows_done, hipEventDisableTiming));
+  return SPP_OK;
+}
+
+hipStream_t sampler_comm_stream(spp_sampler* s) {
+  if (!s->comm_stream && hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess)
+    s->comm_stream = nullptr;
+  return s->comm_stream;
+}
+
+void sampler_poison_comm_stream(spp_sampler* s) { s->comm_stream = nullptr; }  // leaked on purpose
+
+hipEvent_t sampler_export_event(spp_sampler* s, int slot) { return s->slots[(size_t)slot].exported; }
+
+hipEvent_t sampler_inputs_event(spp_sampler* s) {
+  if (!s->inputs_ready && hipEventCreateWithFlags(&s->inputs_ready, hipEventDisableTiming) != hipSuccess)
+    s->inputs_ready = nullptr;
+  return s->inputs_ready;
 }
 
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot) {

@@ -1,9 +1,67 @@
 // Internal (non-ABI) interface between sampler.hip and session.hip: grouped launches.
 #pragma once
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "spp_internal.h"
 
 namespace spp {
+
+// A host thread that outlives Sessions (owned by the pooled sampler): a Session per epoch used to
+// start and join its own launcher thread, and the HIP runtime's per-thread set-up / teardown showed up
+// as a ~75 ms stall of whichever thread was inside a HIP call every few epochs.
+class Worker {
+ public:
+  ~Worker() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  // run `fn` on the worker thread (one task at a time; waits for the previous one to finish first)
+  void run(std::function<void()> fn) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return !busy_; });
+    task_ = std::move(fn);
+    busy_ = true;
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    lk.unlock();
+    cv_.notify_all();
+  }
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return !busy_; });
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [this] { return quit_ || (busy_ && task_); });
+      if (quit_) return;
+      std::function<void()> fn = std::move(task_);
+      task_ = nullptr;
+      lk.unlock();
+      fn();
+      lk.lock();
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::function<void()> task_;
+  bool busy_ = false, quit_ = false;
+};
+
+// the sampler's two persistent host threads: 0 = chain launcher, 1 = exchange issuer
+Worker* sampler_worker(spp_sampler* s, int which);
 
 constexpr int kMaxGroup = 16;       // batches one launch can process (blockIdx.y)
 constexpr int kMaxWorkStreams = 4;  // sampling streams owned by a sampler (one per slot-set in flight)
@@ -75,11 +133,29 @@ struct XBuf {
   char* recv_rows = nullptr;    // rows received for this rank's batches (peer-major, then batch)
   int64_t recv_rows_cap = 0;    // rows
   int64_t row_bytes = 0;        // row size the row buffers were sized for
+  // request-count staging of the set's exchange and its two events (kept here so that a Session per
+  // epoch neither pins host memory nor creates HIP objects)
+  int64_t* cnt_dev = nullptr;
+  int64_t* cnt_host = nullptr;  // pinned mirror
+  int64_t cnt_bytes = 0;
+  hipEvent_t cnt_ready = nullptr;
+  hipEvent_t rows_done = nullptr;
 };
+// make sure the set's count staging holds `bytes` bytes and its events exist
+spp_status sampler_xbuf_counts(spp_sampler* s, XBuf* xb, int64_t bytes);
+// the sampler's persistent stream for the native exchange; `poisoned` = the previous one can never drain
+// (aborted communicator): forget it and hand out a fresh one next time
+hipStream_t sampler_comm_stream(spp_sampler* s);
+void sampler_poison_comm_stream(spp_sampler* s);
 XBuf* sampler_xbuf(spp_sampler* s, int set);
 // grow *buf (capacity *cap, in units of unit_bytes) to at least `need`; the outgrown buffer is kept
 // until the sampler is destroyed (kernels in flight may still read it)
 spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes);
+// Persistent per-slot "the consumer's copies out of this slot are done" events and one "session inputs
+// are ready" event, owned by the sampler: a Session per epoch that created and destroyed ~35 HIP events
+// saw its teardown take 35-80 ms every few epochs (the runtime recycling its signal pool).
+hipEvent_t sampler_export_event(spp_sampler* s, int slot);
+hipEvent_t sampler_inputs_event(spp_sampler* s);
 // completion event of the group `slot` belongs to (NULL when nothing was sampled into it)
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot);
 

@@ -95,7 +95,7 @@ struct spp_session {
   // Launcher thread: enqueues the ~40 kernel launches of a group's chain off the consumer thread
   // (they cost 0.2-0.5 ms of host time per group, which used to stall the consumer at every group
   // boundary).  It is the counterpart of the reference's worker threads, with the GPU doing the work.
-  std::thread launcher;
+  bool launcher_running = false;         // launcher_main is running on the sampler's worker thread 0
   std::mutex mu;
   std::condition_variable cv;
   int64_t groups_consumed = 0;           // groups fully consumed by the caller (guarded by mu)
@@ -112,7 +112,7 @@ struct spp_session {
   int P = 0, rank = 0;
   int64_t rank_offset = 0;
   hipStream_t comm_stream = nullptr;
-  std::thread exchanger;
+  bool exchanger_running = false;        // exchanger_main is running on worker thread 1
   bool issue_on_consumer = false;        // exchanges are issued by the consumer thread at fixed program points
   int64_t exchange_launched = 0;         // groups whose exchange was enqueued (guarded by mu)
   spp_status exchange_rc = SPP_OK;
@@ -461,16 +461,18 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   s->P = part.num_parts;
   s->rank = part.rank;
   s->rank_offset = part.offsets[part.rank];
-  SPP_HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  s->comm_stream = sampler_comm_stream(s->sampler);  // persistent, owned by the (pooled) sampler
+  SPP_REQUIRE(s->comm_stream, "spp_session_create: no stream for the exchange");
   s->xsets.resize((size_t)s->num_sets);
   const size_t cnt_elems = (size_t)s->G * (size_t)s->P;
   for (size_t k = 0; k < s->xsets.size(); ++k) s->xsets[k].b = sampler_xbuf(s->sampler, (int)k);
   for (auto& x : s->xsets) {
     const size_t cnt_bytes = 8 * (cnt_elems * (size_t)(s->P + 2) + 2 * (size_t)s->P + 2);  // + the creation-time check
-    SPP_HIP_TRY(hipMalloc((void**)&x.cnt_dev, cnt_bytes));
-    SPP_HIP_TRY(hipHostMalloc((void**)&x.cnt_host, cnt_bytes, hipHostMallocDefault));
-    SPP_HIP_TRY(hipEventCreateWithFlags(&x.cnt_ready, hipEventDisableTiming));
-    SPP_HIP_TRY(hipEventCreateWithFlags(&x.rows_done, hipEventDisableTiming));
+    SPP_TRY(sampler_xbuf_counts(s->sampler, x.b, (int64_t)cnt_bytes));
+    x.cnt_dev = x.b->cnt_dev;
+    x.cnt_host = x.b->cnt_host;
+    x.cnt_ready = x.b->cnt_ready;
+    x.rows_done = x.b->rows_done;
   }
   // Collective sanity check: the exchange is one collective sequence per group, so every rank must
   // run the same number of batches in groups of the same size (force_exact_num_batches in the
@@ -513,19 +515,14 @@ static void exchange_teardown(spp_session* s) {
       std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     if (!drained) {
+      sampler_poison_comm_stream(s->sampler);  // a later Session gets a fresh stream; this one is leaked
       s->comm_stream = nullptr;
       s->xsets.clear();
       return;
     }
   }
+  // stream, count staging and events belong to the sampler: drain, keep
   if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
-  for (auto& x : s->xsets) {
-    if (x.cnt_dev) (void)hipFree(x.cnt_dev);
-    if (x.cnt_host) (void)hipHostFree(x.cnt_host);
-    if (x.cnt_ready) (void)hipEventDestroy(x.cnt_ready);
-    if (x.rows_done) (void)hipEventDestroy(x.rows_done);
-  }
-  if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
 }
 
 extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session** out) {
@@ -604,24 +601,18 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   s->num_sets = sets;
   s->num_groups = (nb + G - 1) / G;
 
-  auto mk_event = [&](hipEvent_t* ev) {
-    if (rc == SPP_OK && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) {
-      set_error("spp_session_create: hipEventCreate failed");
-      rc = SPP_ERR_HIP;
-    }
-  };
   s->streams.assign((size_t)sets, nullptr);
   for (int i = 0; i < sets; ++i) s->streams[(size_t)i] = sampler_work_stream(s->sampler, i);
+  // the events live in the (pooled) sampler: a Session creates no HIP objects of its own
   s->export_done.assign((size_t)(sets * G), nullptr);
   s->export_recorded.assign((size_t)(sets * G), 0);
-  for (auto& e : s->export_done) mk_event(&e);
+  for (size_t k = 0; k < s->export_done.size(); ++k) s->export_done[k] = sampler_export_event(s->sampler, (int)k);
   if (rc == SPP_OK && cfg->exchange) rc = exchange_setup(s, cfg->exchange, want);
   // Order every stream the session launches on after the producer of its device inputs (seed ids
   // written by a shuffle kernel still queued on the caller's stream, a cache map just built, ...).
-  hipEvent_t inputs_ready = nullptr;
   if (rc == SPP_OK && cfg->order_after_input_stream) {
-    mk_event(&inputs_ready);
-    if (rc == SPP_OK && hipEventRecord(inputs_ready, as_stream(cfg->input_stream)) != hipSuccess) {
+    hipEvent_t inputs_ready = sampler_inputs_event(s->sampler);
+    if (!inputs_ready || hipEventRecord(inputs_ready, as_stream(cfg->input_stream)) != hipSuccess) {
       set_error("spp_session_create: recording the input event failed");
       rc = SPP_ERR_HIP;
     }
@@ -635,7 +626,6 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
     after_inputs(as_stream(spp_sampler_deliver_stream(s->sampler)));
     if (s->comm_stream) after_inputs(s->comm_stream);
   }
-  if (inputs_ready) (void)hipEventDestroy(inputs_ready);  // the waits already enqueued keep their reference
   // mt19937 streams of the whole epoch: generated once per range table, kept by the (pooled) sampler
   if (rc == SPP_OK && nb > 0) {
     std::vector<uint32_t> seeds((size_t)nb);
@@ -650,8 +640,13 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
         }
   }
   if (rc == SPP_OK) {
-    s->launcher = std::thread(launcher_main, s);  // primes the pipeline right away
-    if (s->tr && !s->issue_on_consumer) s->exchanger = std::thread(exchanger_main, s);
+    // both run on host threads that belong to the (pooled) sampler and outlive this Session
+    sampler_worker(s->sampler, 0)->run([s] { launcher_main(s); });  // primes the pipeline right away
+    s->launcher_running = true;
+    if (s->tr && !s->issue_on_consumer) {
+      sampler_worker(s->sampler, 1)->run([s] { exchanger_main(s); });
+      s->exchanger_running = true;
+    }
     if (s->num_groups > 0) rc = wait_group_launched(s, 0);
   }
   if (rc != SPP_OK) {
@@ -664,15 +659,15 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 
 extern "C" void spp_session_destroy(spp_session* s) {
   if (!s) return;
-  if (s->launcher.joinable()) {
+  if (s->launcher_running || s->exchanger_running) {
     {
       std::lock_guard<std::mutex> lk(s->mu);
       s->stop = true;
     }
     s->cv.notify_all();
-    s->launcher.join();
+    if (s->launcher_running) sampler_worker(s->sampler, 0)->wait_idle();
+    if (s->exchanger_running) sampler_worker(s->sampler, 1)->wait_idle();  // it leaves after the group in hand
   }
-  if (s->exchanger.joinable()) s->exchanger.join();  // `stop` is set; it leaves after the group in hand
   (void)hipSetDevice(s->cfg.device);
   const bool had_comm_stream = s->comm_stream != nullptr;
   exchange_teardown(s);
@@ -689,8 +684,6 @@ extern "C" void spp_session_destroy(spp_session* s) {
   for (size_t k = 0; k < s->export_done.size(); ++k)
     if (s->export_done[k] && s->export_recorded[k]) (void)hipEventSynchronize(s->export_done[k]);
   if (s->sampler && s->owns_sampler) spp_sampler_destroy(s->sampler);
-  for (auto ev : s->export_done)
-    if (ev) (void)hipEventDestroy(ev);
   delete s;
 }
 
