@@ -455,6 +455,33 @@ spp_status spp_gat_backward(const int64_t* rowptr_dev, const int64_t* col_dev, i
                             const float* row_sum_dev, const float* grad_out_dev, float* grad_h_dev,
                             float* grad_a_src_dev, float* grad_a_dst_dev, void* stream);
 
+/* GATConv in aggregate-then-project form (same function, far less work: see csrc/aggregate.hip).
+ * With v_src = W^T att_src, v_dst = W^T att_dst (K-vectors):
+ *   spp_gat_logits:            a_src[j] = x_j . v_src (all S rows), a_dst[i] = x_i . v_dst (the first T rows)
+ *   spp_gat_aggregate_forward: z_i = sum_j softmax_j(leaky_relu(a_src[j] + a_dst[i])) x_j  over row i of the hop
+ *                              (diagonal entry dropped, self loop added, as GATConv's set_diag); the layer's
+ *                              output is then z @ W^T.  x rows are fp16 or fp32, K % 4 == 0.
+ *   spp_gat_aggregate_backward: from grad_z: grad_a_src [S] (caller zeroes it), grad_a_dst [T], and -- when
+ *                              grad_x_dev != NULL (caller zeroes it) -- grad_x[j,:] += alpha_ij grad_z_i.
+ *   spp_gat_logits_backward:   grad_v_src[c] = sum_j grad_a_src[j] x[j,c], grad_v_dst[c] = sum_{i<T} grad_a_dst[i] x[i,c]. */
+spp_status spp_gat_logits(const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t num_sources,
+                          int64_t num_targets, int64_t K, const float* v_src_dev, const float* v_dst_dev,
+                          float* a_src_dev, float* a_dst_dev, void* stream);
+spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t num_sources,
+                                   int64_t num_targets, int64_t K, const float* grad_a_src_dev,
+                                   const float* grad_a_dst_dev, float* grad_v_src_dev, float* grad_v_dst_dev,
+                                   void* stream);
+spp_status spp_gat_aggregate_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                     const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                     const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                     float* z_dev, float* row_max_dev, float* row_sum_dev, void* stream);
+spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                      const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                      const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                      const float* z_dev, const float* row_max_dev, const float* row_sum_dev,
+                                      const float* grad_z_dev, float* grad_x_dev, float* grad_a_src_dev,
+                                      float* grad_a_dst_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

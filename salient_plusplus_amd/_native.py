@@ -116,6 +116,10 @@ SIGNATURES = {
     "spp_relu_dropout_forward": (C.c_int, [p, i64, C.c_float, i32, C.c_uint64, p, p]),
     "spp_relu_dropout_backward": (C.c_int, [p, p, i64, C.c_float, p, p]),
     "spp_gat_forward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p]),
+    "spp_gat_logits": (C.c_int, [p, i32, i64, i64, i64, i64, p, p, p, p, p]),
+    "spp_gat_logits_backward": (C.c_int, [p, i32, i64, i64, i64, i64, p, p, p, p, p]),
+    "spp_gat_aggregate_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p]),
+    "spp_gat_aggregate_backward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
     "spp_gat_backward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
     "spp_session_try_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
     "spp_session_quiesce": (C.c_int, [p]),

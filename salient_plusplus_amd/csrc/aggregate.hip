@@ -489,7 +489,290 @@ __global__ __launch_bounds__(kAggNT) void k_gat_bwd(const int64_t* __restrict__ 
   if (lane == 0) grad_a_dst[t] = gad;
 }
 
+// ================================================================================================
+// GATConv, aggregate-then-project form.  GATConv computes h = W x for every SOURCE row and then
+//   out_i = sum_j alpha_ij h_j,   alpha_ij = softmax_j(leaky_relu(att_src . h_j + att_dst . h_i)).
+// Both uses of h are linear in x:  att_src . (W x_j) = x_j . (W^T att_src)  and  sum_j alpha_ij W x_j =
+// W (sum_j alpha_ij x_j).  So the attention logits come from two K-vectors v_src = W^T att_src and
+// v_dst = W^T att_dst, the aggregation runs over the RAW rows (128-wide fp16 in layer 1 instead of
+// 256-wide fp32) and only the T aggregated target rows are projected: layer 1 of the papers-scale batch
+// drops from a 947 k-row GEMM (62 GFLOP, and as much again for its weight gradient) to a 164 k-row one.
+// ================================================================================================
+__device__ __forceinline__ f4 load4v(const float* p) { return load4(p); }
+
+// a_src[j] = x_j . v_src  (all S rows);  a_dst[j] = x_j . v_dst  (the first T rows: the targets)
+template <typename Tin>
+__global__ __launch_bounds__(kAggNT) void k_rowdot2(const Tin* __restrict__ x, int64_t x_stride, int64_t S, int64_t T,
+                                                    int64_t K, const float* __restrict__ v_src,
+                                                    const float* __restrict__ v_dst, int lpr_log2,
+                                                    float* __restrict__ a_src, float* __restrict__ a_dst) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (lpr - 1);
+  const int64_t j = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
+  float ds = 0.f, dd = 0.f;
+  if (j < S) {
+    for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpr * 4) {
+      const f4 xv = load4(x + j * x_stride + c);
+      const f4 vs = load4v(v_src + c);
+      ds += xv.x * vs.x + xv.y * vs.y + xv.z * vs.z + xv.w * vs.w;
+      if (j < T) {
+        const f4 vd = load4v(v_dst + c);
+        dd += xv.x * vd.x + xv.y * vd.y + xv.z * vd.z + xv.w * vd.w;
+      }
+    }
+  }
+  for (int d = lpr >> 1; d >= 1; d >>= 1) {  // the lpr lanes of a row are consecutive lanes of one wavefront
+    ds += __shfl_xor(ds, d, kWave);
+    dd += __shfl_xor(dd, d, kWave);
+  }
+  if (j < S && lane == 0) {
+    a_src[j] = ds;
+    if (j < T) a_dst[j] = dd;
+  }
+}
+
+// out_src[c] += sum_j w_src[j] x[j,c] over all rows; out_dst[c] += sum_{j<T} w_dst[j] x[j,c]   (out zeroed by the caller)
+template <typename Tin>
+__global__ __launch_bounds__(kAggNT) void k_colsum2(const Tin* __restrict__ x, int64_t x_stride, int64_t S, int64_t T,
+                                                    int64_t K, const float* __restrict__ w_src,
+                                                    const float* __restrict__ w_dst, int64_t rows_per_wg,
+                                                    float* __restrict__ out_src, float* __restrict__ out_dst) {
+  __shared__ float red[2][kAggNT][4];
+  const int groups = (int)(K / 4);              // threads that share a row (K/4 <= kAggNT)
+  const int cg = threadIdx.x % groups;          // this thread's 4 columns
+  const int rsub = threadIdx.x / groups, rstep = kAggNT / groups;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < S ? r0 + rows_per_wg : S;
+  f4 as = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f};
+  if (rsub < rstep) {
+    for (int64_t j = r0 + rsub; j < r1; j += rstep) {
+      const f4 xv = load4(x + j * x_stride + (int64_t)cg * 4);
+      const float ws = w_src[j];
+      as.x += ws * xv.x; as.y += ws * xv.y; as.z += ws * xv.z; as.w += ws * xv.w;
+      if (j < T) {
+        const float wd = w_dst[j];
+        ad.x += wd * xv.x; ad.y += wd * xv.y; ad.z += wd * xv.z; ad.w += wd * xv.w;
+      }
+    }
+  }
+  red[0][threadIdx.x][0] = as.x; red[0][threadIdx.x][1] = as.y; red[0][threadIdx.x][2] = as.z; red[0][threadIdx.x][3] = as.w;
+  red[1][threadIdx.x][0] = ad.x; red[1][threadIdx.x][1] = ad.y; red[1][threadIdx.x][2] = ad.z; red[1][threadIdx.x][3] = ad.w;
+  __syncthreads();
+  if (threadIdx.x < groups) {  // one thread per column group sums the row sub-lanes, then one atomic per column
+    float s4[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int r = 0; r < rstep; ++r)
+      for (int q = 0; q < 4; ++q) {
+        s4[0][q] += red[0][r * groups + threadIdx.x][q];
+        s4[1][q] += red[1][r * groups + threadIdx.x][q];
+      }
+    for (int q = 0; q < 4; ++q) {
+      unsafeAtomicAdd(out_src + threadIdx.x * 4 + q, s4[0][q]);
+      if (r0 < T) unsafeAtomicAdd(out_dst + threadIdx.x * 4 + q, s4[1][q]);
+    }
+  }
+}
+
+// z_i = sum_j alpha_ij x_j over row i (its diagonal entry dropped) plus the self loop; x rows fp16 or fp32,
+// 4 columns per lane, online softmax (every lane of a row's group walks the same edges)
+template <typename Tin>
+__global__ __launch_bounds__(kAggNT) void k_gat_agg_fwd(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                        int64_t T, const Tin* __restrict__ x, int64_t x_stride, int64_t K,
+                                                        const float* __restrict__ a_src, const float* __restrict__ a_dst,
+                                                        float slope, int lpr_log2, float* __restrict__ z,
+                                                        float* __restrict__ row_max, float* __restrict__ row_sum) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (lpr - 1);
+  const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
+  if (t >= T) return;
+  const int64_t b = rowptr[t], e = rowptr[t + 1];
+  const float ad = a_dst[t];
+  const float self = lrelu(a_src[t] + ad, slope);
+  for (int64_t c = (int64_t)lane * 4; c < K || c == (int64_t)lane * 4; c += (int64_t)lpr * 4) {
+    const bool has = c < K;
+    f4 acc = has ? load4(x + t * x_stride + c) : f4{0.f, 0.f, 0.f, 0.f};
+    float mm = self, ss = 1.f;
+    for (int64_t k = b; k < e; ++k) {
+      const int64_t j = col[k];
+      if (j == t) continue;  // set_diag drops existing diagonal entries
+      const float sc = lrelu(a_src[j] + ad, slope);
+      const f4 xv = has ? load4(x + j * x_stride + c) : f4{0.f, 0.f, 0.f, 0.f};
+      if (sc > mm) {
+        const float r = __expf(mm - sc);
+        acc.x *= r; acc.y *= r; acc.z *= r; acc.w *= r;
+        ss *= r;
+        mm = sc;
+      }
+      const float w = __expf(sc - mm);
+      ss += w;
+      acc.x += w * xv.x; acc.y += w * xv.y; acc.z += w * xv.z; acc.w += w * xv.w;
+    }
+    if (has) {
+      const float inv = 1.f / ss;
+      *reinterpret_cast<float4*>(z + t * K + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+    if (lane == 0 && c == 0) {
+      row_max[t] = mm;
+      row_sum[t] = ss;
+    }
+  }
+}
+
+// One wavefront per target i:  grad_e_ij = alpha_ij (g_i . x_j - g_i . z_i) lrelu'(raw);  grad_a_src[j] += grad_e_ij;
+// grad_a_dst[i] = sum_j grad_e_ij;  grad_x[j,:] += alpha_ij g_i  (only when grad_x != NULL: the first layer's
+// input needs no gradient, which saves E x K atomics)
+template <typename Tin>
+__global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                        int64_t T, const Tin* __restrict__ x, int64_t x_stride, int64_t K,
+                                                        const float* __restrict__ a_src, const float* __restrict__ a_dst,
+                                                        float slope, const float* __restrict__ z,
+                                                        const float* __restrict__ row_max, const float* __restrict__ row_sum,
+                                                        const float* __restrict__ g, float* __restrict__ grad_x,
+                                                        float* __restrict__ grad_a_src, float* __restrict__ grad_a_dst) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) / kWave;
+  if (t >= T) return;
+  const int64_t b = rowptr[t], e = rowptr[t + 1];
+  const float ad = a_dst[t], m = row_max[t], inv_s = 1.f / row_sum[t];
+  float go = 0.f;  // g_i . z_i
+  for (int64_t c = (int64_t)lane * 4; c < K; c += kWave * 4) {
+    const f4 gv = load4(g + t * K + c), zv = load4(z + t * K + c);
+    go += gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w;
+  }
+#pragma unroll
+  for (int d = kWave / 2; d >= 1; d >>= 1) go += __shfl_xor(go, d, kWave);
+  float gad = 0.f;
+  for (int64_t k = b - 1; k < e; ++k) {  // k == b-1 stands for the self loop
+    const int64_t j = (k < b) ? t : col[k];
+    if (k >= b && j == t) continue;
+    const float raw = a_src[j] + ad;
+    const float a = __expf(lrelu(raw, slope) - m) * inv_s;
+    float gh = 0.f;  // g_i . x_j
+    for (int64_t c = (int64_t)lane * 4; c < K; c += kWave * 4) {
+      const f4 gv = load4(g + t * K + c), xv = load4(x + j * x_stride + c);
+      gh += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
+      if (grad_x) {
+        float* gx = grad_x + j * K + c;
+        unsafeAtomicAdd(gx + 0, a * gv.x);
+        unsafeAtomicAdd(gx + 1, a * gv.y);
+        unsafeAtomicAdd(gx + 2, a * gv.z);
+        unsafeAtomicAdd(gx + 3, a * gv.w);
+      }
+    }
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) gh += __shfl_xor(gh, d, kWave);
+    const float ge = a * (gh - go) * (raw > 0.f ? 1.f : slope);
+    gad += ge;
+    if (lane == 0) unsafeAtomicAdd(grad_a_src + j, ge);
+  }
+  if (lane == 0) grad_a_dst[t] = gad;
+}
+
 }  // namespace spp
+
+static spp_status gat_check(int64_t K, const void* x, int64_t x_stride, int32_t is_half, const char* who) {
+  const int64_t esz = is_half ? 2 : 4;
+  SPP_REQUIRE(K > 0 && K % 4 == 0 && K / 4 <= spp::kAggNT && x_stride >= K && (x_stride * esz) % (4 * esz) == 0 &&
+                  reinterpret_cast<uintptr_t>(x) % (4 * esz) == 0,
+              "%s: needs K %% 4 == 0, K <= %d and rows aligned to 4 elements", who, 4 * spp::kAggNT);
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_gat_logits(const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t num_sources,
+                                     int64_t num_targets, int64_t K, const float* v_src_dev, const float* v_dst_dev,
+                                     float* a_src_dev, float* a_dst_dev, void* stream) {
+  SPP_REQUIRE(num_sources >= num_targets && num_targets >= 0, "spp_gat_logits: bad sizes");
+  if (num_sources == 0) return SPP_OK;
+  SPP_TRY(gat_check(K, x_dev, x_stride_elems, x_is_half, "spp_gat_logits"));
+  SPP_REQUIRE(v_src_dev && v_dst_dev && a_src_dev && (a_dst_dev || num_targets == 0) &&
+                  reinterpret_cast<uintptr_t>(v_src_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(v_dst_dev) % 16 == 0,
+              "spp_gat_logits: NULL or unaligned buffer");
+  const int lpr_log2 = lanes_log2(K / 4);
+  const unsigned grid = (unsigned)ceil_div(num_sources << lpr_log2, kAggNT);
+  if (x_is_half)
+    hipLaunchKernelGGL(k_rowdot2<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), static_cast<const __half*>(x_dev),
+                       x_stride_elems, num_sources, num_targets, K, v_src_dev, v_dst_dev, lpr_log2, a_src_dev, a_dst_dev);
+  else
+    hipLaunchKernelGGL(k_rowdot2<float>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), static_cast<const float*>(x_dev),
+                       x_stride_elems, num_sources, num_targets, K, v_src_dev, v_dst_dev, lpr_log2, a_src_dev, a_dst_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_half, int64_t x_stride_elems,
+                                              int64_t num_sources, int64_t num_targets, int64_t K,
+                                              const float* grad_a_src_dev, const float* grad_a_dst_dev,
+                                              float* grad_v_src_dev, float* grad_v_dst_dev, void* stream) {
+  SPP_REQUIRE(num_sources >= num_targets && num_targets >= 0, "spp_gat_logits_backward: bad sizes");
+  SPP_TRY(gat_check(K, x_dev, x_stride_elems, x_is_half, "spp_gat_logits_backward"));
+  SPP_REQUIRE(grad_v_src_dev && grad_v_dst_dev, "spp_gat_logits_backward: NULL output");
+  hipStream_t st = as_stream(stream);
+  SPP_HIP_TRY(hipMemsetAsync(grad_v_src_dev, 0, sizeof(float) * (size_t)K, st));
+  SPP_HIP_TRY(hipMemsetAsync(grad_v_dst_dev, 0, sizeof(float) * (size_t)K, st));
+  if (num_sources == 0) return SPP_OK;
+  SPP_REQUIRE(grad_a_src_dev && (grad_a_dst_dev || num_targets == 0), "spp_gat_logits_backward: NULL input");
+  const int64_t rows_per_wg = 2048;
+  const unsigned grid = (unsigned)ceil_div(num_sources, rows_per_wg);
+  if (x_is_half)
+    hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
+                       num_sources, num_targets, K, grad_a_src_dev, grad_a_dst_dev, rows_per_wg, grad_v_src_dev,
+                       grad_v_dst_dev);
+  else
+    hipLaunchKernelGGL(k_colsum2<float>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const float*>(x_dev), x_stride_elems,
+                       num_sources, num_targets, K, grad_a_src_dev, grad_a_dst_dev, rows_per_wg, grad_v_src_dev,
+                       grad_v_dst_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_gat_aggregate_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                                const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                                float* z_dev, float* row_max_dev, float* row_sum_dev, void* stream) {
+  SPP_REQUIRE(num_targets >= 0, "spp_gat_aggregate_forward: negative size");
+  if (num_targets == 0) return SPP_OK;
+  SPP_TRY(gat_check(K, x_dev, x_stride_elems, x_is_half, "spp_gat_aggregate_forward"));
+  SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev &&
+                  reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_forward: NULL or unaligned buffer");
+  const int lpr_log2 = lanes_log2(K / 4);
+  const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
+  if (x_is_half)
+    hipLaunchKernelGGL(k_gat_agg_fwd<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
+                       num_targets, static_cast<const __half*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
+                       negative_slope, lpr_log2, z_dev, row_max_dev, row_sum_dev);
+  else
+    hipLaunchKernelGGL(k_gat_agg_fwd<float>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
+                       num_targets, static_cast<const float*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
+                       negative_slope, lpr_log2, z_dev, row_max_dev, row_sum_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                 const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                                 const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                                 const float* z_dev, const float* row_max_dev, const float* row_sum_dev,
+                                                 const float* grad_z_dev, float* grad_x_dev /* NULL: not wanted */,
+                                                 float* grad_a_src_dev, float* grad_a_dst_dev, void* stream) {
+  SPP_REQUIRE(num_targets >= 0, "spp_gat_aggregate_backward: negative size");
+  if (num_targets == 0) return SPP_OK;
+  SPP_TRY(gat_check(K, x_dev, x_stride_elems, x_is_half, "spp_gat_aggregate_backward"));
+  SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev &&
+                  grad_a_src_dev && grad_a_dst_dev && reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_backward: NULL or unaligned buffer");
+  const unsigned grid = (unsigned)ceil_div(num_targets * kWave, kAggNT);
+  if (x_is_half)
+    hipLaunchKernelGGL(k_gat_agg_bwd<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
+                       num_targets, static_cast<const __half*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
+                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, grad_x_dev, grad_a_src_dev,
+                       grad_a_dst_dev);
+  else
+    hipLaunchKernelGGL(k_gat_agg_bwd<float>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
+                       num_targets, static_cast<const float*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
+                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, grad_x_dev, grad_a_src_dev,
+                       grad_a_dst_dev);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
 
 extern "C" spp_status spp_gat_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                       const float* h_dev, int64_t F, const float* a_src_dev, const float* a_dst_dev,

@@ -265,3 +265,33 @@ def test_relu_dropout_fused():
     assert not torch.equal(relu_dropout(x, 0.5, True), y.detach())
     kept25 = float((relu_dropout(x, 0.75, True)[pos] > 0).float().mean())
     assert 0.24 < kept25 < 0.26, kept25
+
+
+@pytest.mark.parametrize("K,N,dtype", [(128, 256, torch.float16), (256, 64, torch.float32), (100, 47, torch.float32)])
+def test_gat_layer_aggregate_then_project_matches_project_then_aggregate(K, N, dtype):
+    """_GatLayer (logits from W^T att, aggregation of the raw rows, projection of the targets only) against
+    GATConv's own order of operations written with plain torch ops: forward and every gradient."""
+    from salient_plusplus_amd.models import _GatLayer
+    T, S = 1500, 6000
+    rowptr, col = _random_hop(T, S, 12, K + N)
+    col[::13] = torch.repeat_interleave(torch.arange(T, device="cuda"), rowptr[1:] - rowptr[:-1])[::13]   # diagonal entries
+    g = torch.Generator().manual_seed(4)
+    x0 = (0.5 * torch.randn((S, K), generator=g)).to(dtype).cuda()
+    W0 = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+    as0, ad0 = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    need_gx = dtype == torch.float32
+    xa = x0.clone().requires_grad_(need_gx)
+    xb = x0.clone().float().requires_grad_(need_gx)
+    pa = [t.clone().requires_grad_(True) for t in (W0, as0, ad0)]
+    pb = [t.clone().requires_grad_(True) for t in (W0, as0, ad0)]
+    out_a = _GatLayer.apply(xa, pa[0], pa[1], pa[2], rowptr, col, T, 0.2)
+    h = xb @ pb[0].t()                                        # PyG's order: project every source row
+    out_b = _ref_gat(h, h @ pb[1], h[:T] @ pb[2], rowptr, col, T)
+    torch.testing.assert_close(out_a, out_b, rtol=2e-4, atol=2e-5)
+    w = torch.randn((T, N), device="cuda")
+    (out_a * w).sum().backward()
+    (out_b * w).sum().backward()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.grad, b.grad, rtol=2e-3, atol=2e-4)
+    if need_gx:
+        torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-3, atol=2e-4)
