@@ -545,7 +545,20 @@ __global__ __launch_bounds__(kAggNT) void k_colsum2(const Tin* __restrict__ x, i
   const int64_t r1 = r0 + rows_per_wg < S ? r0 + rows_per_wg : S;
   f4 as = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f};
   if (rsub < rstep) {
-    for (int64_t j = r0 + rsub; j < r1; j += rstep) {
+    int64_t j = r0 + rsub;
+    for (; j + rstep < r1; j += 2 * rstep) {  // two independent rows in flight
+      const int64_t j1 = j + rstep;
+      const f4 x0 = load4(x + j * x_stride + (int64_t)cg * 4), x1 = load4(x + j1 * x_stride + (int64_t)cg * 4);
+      const float w0 = w_src[j], w1 = w_src[j1];
+      as.x += w0 * x0.x + w1 * x1.x; as.y += w0 * x0.y + w1 * x1.y;
+      as.z += w0 * x0.z + w1 * x1.z; as.w += w0 * x0.w + w1 * x1.w;
+      if (j < T) {
+        const float d0 = w_dst[j], d1 = j1 < T ? w_dst[j1] : 0.f;
+        ad.x += d0 * x0.x + d1 * x1.x; ad.y += d0 * x0.y + d1 * x1.y;
+        ad.z += d0 * x0.z + d1 * x1.z; ad.w += d0 * x0.w + d1 * x1.w;
+      }
+    }
+    if (j < r1) {
       const f4 xv = load4(x + j * x_stride + (int64_t)cg * 4);
       const float ws = w_src[j];
       as.x += ws * xv.x; as.y += ws * xv.y; as.z += ws * xv.z; as.w += ws * xv.w;
@@ -626,45 +639,64 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
                                                         const float* __restrict__ a_src, const float* __restrict__ a_dst,
                                                         float slope, const float* __restrict__ z,
                                                         const float* __restrict__ row_max, const float* __restrict__ row_sum,
-                                                        const float* __restrict__ g, float* __restrict__ grad_x,
+                                                        const float* __restrict__ g, int lpt_log2, float* __restrict__ grad_x,
                                                         float* __restrict__ grad_a_src, float* __restrict__ grad_a_dst) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) / kWave;
-  if (t >= T) return;
-  const int64_t b = rowptr[t], e = rowptr[t + 1];
-  const float ad = a_dst[t], m = row_max[t], inv_s = 1.f / row_sum[t];
+  // lpt = min(64, K/4 rounded up to a power of two) lanes per target: a 128-wide row keeps 32 lanes busy,
+  // so two targets share a wavefront instead of half of it idling
+  const int lpt = 1 << lpt_log2;
+  const int lane = threadIdx.x & (lpt - 1);
+  const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpt_log2;
+  const bool live = t < T;
+  const int64_t b = live ? rowptr[t] : 0, e = live ? rowptr[t + 1] : -1;
+  const float ad = live ? a_dst[t] : 0.f, m = live ? row_max[t] : 0.f, inv_s = live ? 1.f / row_sum[t] : 0.f;
+  auto group_sum = [&](float v) {
+    for (int d = lpt >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+  };
   float go = 0.f;  // g_i . z_i
-  for (int64_t c = (int64_t)lane * 4; c < K; c += kWave * 4) {
-    const f4 gv = load4(g + t * K + c), zv = load4(z + t * K + c);
-    go += gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w;
+  if (live)
+    for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
+      const f4 gv = load4(g + t * K + c), zv = load4(z + t * K + c);
+      go += gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w;
+    }
+  go = group_sum(go);
+  // the targets sharing a wavefront have different degrees: every group runs to the longest row of its
+  // wavefront so that the shuffles stay convergent
+  int64_t n = live ? e - b + 1 : 0;
+  for (int d = lpt; d < kWave; d <<= 1) {
+    const int64_t o = __shfl_xor((long long)n, d, kWave);
+    n = o > n ? o : n;
   }
-#pragma unroll
-  for (int d = kWave / 2; d >= 1; d >>= 1) go += __shfl_xor(go, d, kWave);
   float gad = 0.f;
-  for (int64_t k = b - 1; k < e; ++k) {  // k == b-1 stands for the self loop
-    const int64_t j = (k < b) ? t : col[k];
-    if (k >= b && j == t) continue;
-    const float raw = a_src[j] + ad;
-    const float a = __expf(lrelu(raw, slope) - m) * inv_s;
-    float gh = 0.f;  // g_i . x_j
-    for (int64_t c = (int64_t)lane * 4; c < K; c += kWave * 4) {
-      const f4 gv = load4(g + t * K + c), xv = load4(x + j * x_stride + c);
-      gh += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
-      if (grad_x) {
-        float* gx = grad_x + j * K + c;
-        unsafeAtomicAdd(gx + 0, a * gv.x);
-        unsafeAtomicAdd(gx + 1, a * gv.y);
-        unsafeAtomicAdd(gx + 2, a * gv.z);
-        unsafeAtomicAdd(gx + 3, a * gv.w);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t k = b - 1 + i;  // k == b-1 stands for the self loop
+    const bool on = live && k < e;
+    const int64_t j = !on ? 0 : ((k < b) ? t : col[k]);
+    const bool use = on && !(k >= b && j == t);  // set_diag drops existing diagonal entries
+    float gh = 0.f, a = 0.f, raw = 0.f;
+    if (use) {
+      raw = a_src[j] + ad;
+      a = __expf(lrelu(raw, slope) - m) * inv_s;
+      for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
+        const f4 gv = load4(g + t * K + c), xv = load4(x + j * x_stride + c);
+        gh += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
+        if (grad_x) {
+          float* gx = grad_x + j * K + c;
+          unsafeAtomicAdd(gx + 0, a * gv.x);
+          unsafeAtomicAdd(gx + 1, a * gv.y);
+          unsafeAtomicAdd(gx + 2, a * gv.z);
+          unsafeAtomicAdd(gx + 3, a * gv.w);
+        }
       }
     }
-#pragma unroll
-    for (int d = kWave / 2; d >= 1; d >>= 1) gh += __shfl_xor(gh, d, kWave);
-    const float ge = a * (gh - go) * (raw > 0.f ? 1.f : slope);
-    gad += ge;
-    if (lane == 0) unsafeAtomicAdd(grad_a_src + j, ge);
+    gh = group_sum(gh);
+    if (use) {
+      const float ge = a * (gh - go) * (raw > 0.f ? 1.f : slope);
+      gad += ge;
+      if (lane == 0) unsafeAtomicAdd(grad_a_src + j, ge);
+    }
   }
-  if (lane == 0) grad_a_dst[t] = gad;
+  if (live && lane == 0) grad_a_dst[t] = gad;
 }
 
 }  // namespace spp
@@ -710,7 +742,7 @@ extern "C" spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_ha
   SPP_HIP_TRY(hipMemsetAsync(grad_v_dst_dev, 0, sizeof(float) * (size_t)K, st));
   if (num_sources == 0) return SPP_OK;
   SPP_REQUIRE(grad_a_src_dev && (grad_a_dst_dev || num_targets == 0), "spp_gat_logits_backward: NULL input");
-  const int64_t rows_per_wg = 2048;
+  const int64_t rows_per_wg = 512;  // 256 column atomics per workgroup: 0.5 per row
   const unsigned grid = (unsigned)ceil_div(num_sources, rows_per_wg);
   if (x_is_half)
     hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
@@ -759,16 +791,17 @@ extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, cons
   SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev &&
                   grad_a_src_dev && grad_a_dst_dev && reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_backward: NULL or unaligned buffer");
-  const unsigned grid = (unsigned)ceil_div(num_targets * kWave, kAggNT);
+  const int lpt_log2 = lanes_log2(K / 4);
+  const unsigned grid = (unsigned)ceil_div(num_targets << lpt_log2, kAggNT);
   if (x_is_half)
     hipLaunchKernelGGL(k_gat_agg_bwd<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
                        num_targets, static_cast<const __half*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
-                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, grad_x_dev, grad_a_src_dev,
+                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev,
                        grad_a_dst_dev);
   else
     hipLaunchKernelGGL(k_gat_agg_bwd<float>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
                        num_targets, static_cast<const float*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
-                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, grad_x_dev, grad_a_src_dev,
+                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev,
                        grad_a_dst_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
