@@ -546,19 +546,23 @@ __global__ __launch_bounds__(kAggNT) void k_colsum2(const Tin* __restrict__ x, i
   f4 as = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f};
   if (rsub < rstep) {
     int64_t j = r0 + rsub;
-    for (; j + rstep < r1; j += 2 * rstep) {  // two independent rows in flight
-      const int64_t j1 = j + rstep;
-      const f4 x0 = load4(x + j * x_stride + (int64_t)cg * 4), x1 = load4(x + j1 * x_stride + (int64_t)cg * 4);
-      const float w0 = w_src[j], w1 = w_src[j1];
-      as.x += w0 * x0.x + w1 * x1.x; as.y += w0 * x0.y + w1 * x1.y;
-      as.z += w0 * x0.z + w1 * x1.z; as.w += w0 * x0.w + w1 * x1.w;
-      if (j < T) {
-        const float d0 = w_dst[j], d1 = j1 < T ? w_dst[j1] : 0.f;
-        ad.x += d0 * x0.x + d1 * x1.x; ad.y += d0 * x0.y + d1 * x1.y;
-        ad.z += d0 * x0.z + d1 * x1.z; ad.w += d0 * x0.w + d1 * x1.w;
+    for (; j + 3 * rstep < r1; j += 4 * rstep) {  // four independent rows in flight
+      f4 xv[4];
+      float ws[4], wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t ju = j + u * rstep;
+        xv[u] = load4(x + ju * x_stride + (int64_t)cg * 4);
+        ws[u] = w_src[ju];
+        wd[u] = ju < T ? w_dst[ju] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        as.x += ws[u] * xv[u].x; as.y += ws[u] * xv[u].y; as.z += ws[u] * xv[u].z; as.w += ws[u] * xv[u].w;
+        ad.x += wd[u] * xv[u].x; ad.y += wd[u] * xv[u].y; ad.z += wd[u] * xv[u].z; ad.w += wd[u] * xv[u].w;
       }
     }
-    if (j < r1) {
+    for (; j < r1; j += rstep) {
       const f4 xv = load4(x + j * x_stride + (int64_t)cg * 4);
       const float ws = w_src[j];
       as.x += ws * xv.x; as.y += ws * xv.y; as.z += ws * xv.z; as.w += ws * xv.w;
@@ -641,8 +645,7 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
                                                         const float* __restrict__ row_max, const float* __restrict__ row_sum,
                                                         const float* __restrict__ g, int lpt_log2, float* __restrict__ grad_x,
                                                         float* __restrict__ grad_a_src, float* __restrict__ grad_a_dst) {
-  // lpt = min(64, K/4 rounded up to a power of two) lanes per target: a 128-wide row keeps 32 lanes busy,
-  // so two targets share a wavefront instead of half of it idling
+  // lpt = min(64, K rounded up to a power of two) lanes per target
   const int lpt = 1 << lpt_log2;
   const int lane = threadIdx.x & (lpt - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpt_log2;
@@ -653,12 +656,12 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
     for (int d = lpt >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
     return v;
   };
+  // column c = lane + lpt * i: consecutive lanes touch consecutive columns, so a group's loads and --
+  // what matters -- its fp32 atomics are contiguous 4 * lpt-byte segments (the atomic units run at full
+  // rate on contiguous 256-byte wave instructions and ~17x slower on scattered ones)
   float go = 0.f;  // g_i . z_i
   if (live)
-    for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
-      const f4 gv = load4(g + t * K + c), zv = load4(z + t * K + c);
-      go += gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w;
-    }
+    for (int64_t c = lane; c < K; c += lpt) go += g[t * K + c] * z[t * K + c];
   go = group_sum(go);
   // the targets sharing a wavefront have different degrees: every group runs to the longest row of its
   // wavefront so that the shuffles stay convergent
@@ -677,16 +680,10 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
     if (use) {
       raw = a_src[j] + ad;
       a = __expf(lrelu(raw, slope) - m) * inv_s;
-      for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
-        const f4 gv = load4(g + t * K + c), xv = load4(x + j * x_stride + c);
-        gh += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
-        if (grad_x) {
-          float* gx = grad_x + j * K + c;
-          unsafeAtomicAdd(gx + 0, a * gv.x);
-          unsafeAtomicAdd(gx + 1, a * gv.y);
-          unsafeAtomicAdd(gx + 2, a * gv.z);
-          unsafeAtomicAdd(gx + 3, a * gv.w);
-        }
+      for (int64_t c = lane; c < K; c += lpt) {
+        const float gv = g[t * K + c];
+        gh += gv * load1(x + j * x_stride + c);
+        if (grad_x) unsafeAtomicAdd(grad_x + j * K + c, a * gv);
       }
     }
     gh = group_sum(gh);
@@ -742,7 +739,7 @@ extern "C" spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_ha
   SPP_HIP_TRY(hipMemsetAsync(grad_v_dst_dev, 0, sizeof(float) * (size_t)K, st));
   if (num_sources == 0) return SPP_OK;
   SPP_REQUIRE(grad_a_src_dev && (grad_a_dst_dev || num_targets == 0), "spp_gat_logits_backward: NULL input");
-  const int64_t rows_per_wg = 512;  // 256 column atomics per workgroup: 0.5 per row
+  const int64_t rows_per_wg = 256;  // one column atomic per row and workgroup
   const unsigned grid = (unsigned)ceil_div(num_sources, rows_per_wg);
   if (x_is_half)
     hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
@@ -791,7 +788,7 @@ extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, cons
   SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev &&
                   grad_a_src_dev && grad_a_dst_dev && reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_backward: NULL or unaligned buffer");
-  const int lpt_log2 = lanes_log2(K / 4);
+  const int lpt_log2 = lanes_log2(K);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpt_log2, kAggNT);
   if (x_is_half)
     hipLaunchKernelGGL(k_gat_agg_bwd<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
