@@ -637,7 +637,9 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_fwd(const int64_t* __restric
 // One wavefront per target i:  grad_e_ij = alpha_ij (g_i . x_j - g_i . z_i) lrelu'(raw);  grad_a_src[j] += grad_e_ij;
 // grad_a_dst[i] = sum_j grad_e_ij;  grad_x[j,:] += alpha_ij g_i  (only when grad_x != NULL: the first layer's
 // input needs no gradient, which saves E x K atomics)
-template <typename Tin>
+// kVec: 4 columns per lane (no input gradient wanted: only dot products, 8/16-byte loads);
+// otherwise one column per lane and step, so that the fp32 atomics of a group are contiguous
+template <typename Tin, bool kVec>
 __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                                                         int64_t T, const Tin* __restrict__ x, int64_t x_stride, int64_t K,
                                                         const float* __restrict__ a_src, const float* __restrict__ a_dst,
@@ -660,8 +662,16 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
   // what matters -- its fp32 atomics are contiguous 4 * lpt-byte segments (the atomic units run at full
   // rate on contiguous 256-byte wave instructions and ~17x slower on scattered ones)
   float go = 0.f;  // g_i . z_i
-  if (live)
-    for (int64_t c = lane; c < K; c += lpt) go += g[t * K + c] * z[t * K + c];
+  if (live) {
+    if (kVec) {
+      for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
+        const f4 gv = load4(g + t * K + c), zv = load4(z + t * K + c);
+        go += gv.x * zv.x + gv.y * zv.y + gv.z * zv.z + gv.w * zv.w;
+      }
+    } else {
+      for (int64_t c = lane; c < K; c += lpt) go += g[t * K + c] * z[t * K + c];
+    }
+  }
   go = group_sum(go);
   // the targets sharing a wavefront have different degrees: every group runs to the longest row of its
   // wavefront so that the shuffles stay convergent
@@ -680,10 +690,17 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
     if (use) {
       raw = a_src[j] + ad;
       a = __expf(lrelu(raw, slope) - m) * inv_s;
-      for (int64_t c = lane; c < K; c += lpt) {
-        const float gv = g[t * K + c];
-        gh += gv * load1(x + j * x_stride + c);
-        if (grad_x) unsafeAtomicAdd(grad_x + j * K + c, a * gv);
+      if (kVec) {
+        for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpt * 4) {
+          const f4 gv = load4(g + t * K + c), xv = load4(x + j * x_stride + c);
+          gh += gv.x * xv.x + gv.y * xv.y + gv.z * xv.z + gv.w * xv.w;
+        }
+      } else {
+        for (int64_t c = lane; c < K; c += lpt) {
+          const float gv = g[t * K + c];
+          gh += gv * load1(x + j * x_stride + c);
+          unsafeAtomicAdd(grad_x + j * K + c, a * gv);
+        }
       }
     }
     gh = group_sum(gh);
@@ -739,7 +756,7 @@ extern "C" spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_ha
   SPP_HIP_TRY(hipMemsetAsync(grad_v_dst_dev, 0, sizeof(float) * (size_t)K, st));
   if (num_sources == 0) return SPP_OK;
   SPP_REQUIRE(grad_a_src_dev && (grad_a_dst_dev || num_targets == 0), "spp_gat_logits_backward: NULL input");
-  const int64_t rows_per_wg = 256;  // one column atomic per row and workgroup
+  const int64_t rows_per_wg = 1024;  // 4 rows in flight per lane; K atomics onto the same K addresses per workgroup
   const unsigned grid = (unsigned)ceil_div(num_sources, rows_per_wg);
   if (x_is_half)
     hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
@@ -788,18 +805,20 @@ extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, cons
   SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev &&
                   grad_a_src_dev && grad_a_dst_dev && reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_backward: NULL or unaligned buffer");
-  const int lpt_log2 = lanes_log2(K);
+  const bool vec = grad_x_dev == nullptr;
+  const int lpt_log2 = lanes_log2(vec ? K / 4 : K);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpt_log2, kAggNT);
-  if (x_is_half)
-    hipLaunchKernelGGL(k_gat_agg_bwd<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
-                       num_targets, static_cast<const __half*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
-                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev,
-                       grad_a_dst_dev);
-  else
-    hipLaunchKernelGGL(k_gat_agg_bwd<float>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,
-                       num_targets, static_cast<const float*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,
-                       negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev,
-                       grad_a_dst_dev);
+#define SPP_GAT_BWD(TIN, V)                                                                                            \
+  hipLaunchKernelGGL((k_gat_agg_bwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,       \
+                     num_targets, static_cast<const TIN*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,            \
+                     negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev, \
+                     grad_a_dst_dev)
+  if (x_is_half) {
+    if (vec) SPP_GAT_BWD(__half, true); else SPP_GAT_BWD(__half, false);
+  } else {
+    if (vec) SPP_GAT_BWD(float, true); else SPP_GAT_BWD(float, false);
+  }
+#undef SPP_GAT_BWD
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }
