@@ -365,12 +365,17 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
   if ((int64_t)bx_ * kNT >= T) return;
   int32_t cnt = 0, smp = 0;
   if (i < T) {
-    const int32_t v = s.n_ids[i];
-    const int64_t rs = rowptr[v];
-    const int64_t re = rowptr[v + 1];
-    const int32_t deg = (int32_t)(re - rs);
-    s.deg[i] = deg;
-    s.rowstart[i] = rs;
+    int32_t deg;
+    if (h > 0 && i < s.st->cnt[h - 1]) {
+      deg = s.deg[i];  // a target of the previous hop as well: its degree and row start are still in place
+    } else {
+      const int32_t v = s.n_ids[i];
+      const int64_t rs = rowptr[v];
+      const int64_t re = rowptr[v + 1];
+      deg = (int32_t)(re - rs);
+      s.deg[i] = deg;
+      s.rowstart[i] = rs;
+    }
     target_counts(deg, f, replace, cnt, smp);
   }
   int32_t tc, ts;
