@@ -798,6 +798,16 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   const uint32_t Tprev = h > 0 ? (uint32_t)s.st->cnt[h - 1] : 0u;
   const int32_t e0 = s.boff[b], e1 = s.boff[b + 1];
   const bool work = e1 > e0;  // block-uniform
+  // this hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in registers between the
+  // insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them).  Their loads are
+  // issued FIRST: they depend on nothing but the bucket's bounds, and the known-list phase (two more
+  // dependent global round trips) runs while they are in flight.
+  unsigned long long pr[kDedupRegs];
+#pragma unroll
+  for (int u = 0; u < kDedupRegs; ++u) {
+    const int i = e0 + u * kNT + threadIdx.x;
+    pr[u] = (work && i < e1) ? s.bpairs[i] : kEmptySlot;
+  }
   for (int i = threadIdx.x; i < nf; i += kNT) {
     fkc[i] = s.kcount[fb0 + i];
     fnew[i] = 0;
@@ -841,14 +851,6 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   }
   if (!work) return;
   __syncthreads();
-  // this hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in registers between
-  // the insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them)
-  unsigned long long pr[kDedupRegs];
-#pragma unroll
-  for (int u = 0; u < kDedupRegs; ++u) {
-    const int i = e0 + u * kNT + threadIdx.x;
-    pr[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
-  }
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u)
     if (pr[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
