@@ -22,7 +22,10 @@ template <> struct vec_of<2> { using type = uint16_t; };
 template <> struct vec_of<1> { using type = uint8_t; };
 
 constexpr int kGatherThreads = 256;
-constexpr int kGatherUnroll = 4;
+#ifndef SPP_GATHER_UNROLL
+#define SPP_GATHER_UNROLL 4
+#endif
+constexpr int kGatherUnroll = SPP_GATHER_UNROLL;
 
 struct GatherGeom {
   int vec;        // bytes per lane access (16/8/4/2/1)
