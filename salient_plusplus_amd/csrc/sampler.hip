@@ -167,6 +167,7 @@ struct SlotPtrs {
   int32_t* parts;      // [Ucap] node ids grouped by owner, then (separately) ...
   int32_t* pcached;    // [Ucap] cache rows of the cache hits
   int32_t* pperm;      // [Ucap] perm_partition_to_mfg
+  int2* psrc;          // [Ucap] where node i's feature row comes from: {bucket, row inside the bucket's source}
   uint8_t* pbucket;    // [Ucap] bucket of every node
   int32_t* pblk;       // [P+1][pnblk] per-workgroup bucket counts -> exclusive offsets
 };
@@ -1181,8 +1182,15 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
   const int32_t v = s.n_ids[i];
   const int32_t pos = base[b] + s.pblk[(int64_t)b * a.nblk_cap + bx_] + pre + rank_w;
   s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
-  if (b < a.P) s.parts[pos] = v;
-  else s.pcached[pos - base[a.P]] = a.cache_map[v];  // nid2cachenid (:1256)
+  int32_t src_row;     // for the fused assembly (k_deliver): one record per node instead of pperm -> segment search -> id
+  if (b < a.P) {
+    s.parts[pos] = v;
+    src_row = (b == a.rank) ? (int32_t)((int64_t)v - a.off.v[a.rank]) : pos - base[b];
+  } else {
+    src_row = a.cache_map[v];  // nid2cachenid (:1256)
+    s.pcached[pos - base[a.P]] = src_row;
+  }
+  s.psrc[i] = int2{b, src_row};
 }
 
 // ids requested from the peers, regrouped peer-major across the batches of a group (one send per
@@ -1250,9 +1258,7 @@ struct DeliverArgs {
   const char* recv;
   const char* cache;
   int64_t cache_stride;
-  const int32_t* pperm;
-  const int32_t* pcached;
-  int32_t seg_start[SPP_MAX_PARTS + 2];
+  const int2* psrc;
   int64_t recv_base[SPP_MAX_PARTS];
 };
 
@@ -1268,12 +1274,10 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
       // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes
       move_rows_body<VEC, false>(
           [&](int64_t r) -> const char* {
-            const int32_t j = a.pperm[r];
-            int m = 0;
-            while (m < a.P && j >= a.seg_start[m + 1]) ++m;
-            if (m == a.rank) return a.x_src + ((int64_t)a.n_ids[r] - a.rank_offset) * a.x_src_stride;
-            if (m == a.P) return a.cache + (int64_t)a.pcached[j - a.seg_start[m]] * a.cache_stride;
-            return a.recv + (a.recv_base[m] + (j - a.seg_start[m])) * a.x_row_bytes;
+            const int2 c = a.psrc[r];  // {bucket, row} written by k_gpart_scatter: one load before the row's own
+            if (c.x == a.rank) return a.x_src + (int64_t)c.y * a.x_src_stride;
+            if (c.x == a.P) return a.cache + (int64_t)c.y * a.cache_stride;
+            return a.recv + (a.recv_base[c.x] + c.y) * a.x_row_bytes;
           },
           a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b, a.nb_x);
     }
@@ -1531,6 +1535,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       A(p.parts, int32_t, ucap);
       A(p.pcached, int32_t, ucap);
       A(p.pperm, int32_t, ucap);
+      A(p.psrc, int2, ucap);
       A(p.pbucket, uint8_t, ucap);
       A(p.pblk, int32_t, (int64_t)(s->part.P + 1) * s->part.nblk_cap);
     }
@@ -2006,14 +2011,7 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
     a.rank_offset = s->part.off.v[s->part.rank];
     a.recv = asrc->recv;
     a.cache = asrc->cache;
-    a.pperm = sl.p.pperm;
-    a.pcached = sl.p.pcached;
-    int32_t acc = 0;
-    for (int m = 0; m <= s->part.P; ++m) {
-      a.seg_start[m] = acc;
-      acc += hs->pcnt[m];
-    }
-    a.seg_start[s->part.P + 1] = acc;
+    a.psrc = sl.p.psrc;
     for (int m = 0; m < s->part.P; ++m) a.recv_base[m] = asrc->recv_base[m];
     SPP_REQUIRE(hs->pcnt[s->part.P] == 0 || asrc->cache, "sampler_deliver: cache hits without cache rows");
   }
