@@ -1085,32 +1085,44 @@ struct PartDev {
   int32_t nblk_cap;  // row pitch of pblk
 };
 
+constexpr int kPartRounds = 4;                   // nodes per thread of k_gpart_hist / k_gpart_scatter
+constexpr int kPartSpan = kNT * kPartRounds;     // nodes per workgroup (one row entry of pblk)
+
 __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t H,
                                                     PartDev a) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t cnt[kPartBuckets];
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)bx_ * kNT >= U) return;
+  if ((int64_t)bx_ * kPartSpan >= U) return;
   for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
-  __syncthreads();
-  const int32_t i = bx_ * kNT + threadIdx.x;
-  const bool valid = i < U;
-  int32_t b = -1;
-  if (valid) {
-    b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)s.n_ids[i]);
-    s.pbucket[i] = (uint8_t)b;
+  int32_t v[kPartRounds];
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    v[r] = i < U ? s.n_ids[i] : -1;  // node ids are >= 0
   }
-  // one LDS atomic per (wavefront, bucket present in it) instead of one per node: most nodes of a
-  // wavefront share an owner, and 64 lanes hammering one counter serialise
-  unsigned long long todo = __ballot(valid);
+  __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int32_t lb = __shfl(b, leader, kWave);
-    const unsigned long long m = __ballot(valid && b == lb);
-    if (lane == leader) atomicAdd(&cnt[lb], __popcll(m));
-    todo &= ~m;
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    const bool valid = v[r] >= 0;
+    int32_t b = -1;
+    if (valid) {
+      b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)v[r]);
+      s.pbucket[i] = (uint8_t)b;
+    }
+    // one LDS atomic per (wavefront, bucket present in it) instead of one per node: most nodes of a
+    // wavefront share an owner, and 64 lanes hammering one counter serialise
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int32_t lb = __shfl(b, leader, kWave);
+      const unsigned long long m = __ballot(valid && b == lb);
+      if (lane == leader) atomicAdd(&cnt[lb], __popcll(m));
+      todo &= ~m;
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + bx_] = cnt[k];
@@ -1123,7 +1135,7 @@ __global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restri
   const SlotPtrs& s = slots[gg.first_slot + by_];
   SlotState* st = s.st;
   const int32_t U = st->error ? 0 : st->cnt[H];
-  const int32_t nblk = (U + kNT - 1) / kNT;
+  const int32_t nblk = (U + kPartSpan - 1) / kPartSpan;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   for (int32_t m = wid; m <= a.P; m += kScanNT / kWave) {
     int32_t* row = s.pblk + (int64_t)m * a.nblk_cap;
@@ -1143,13 +1155,14 @@ __global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restri
 __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t H, PartDev a) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t wcnt[kNT / kWave][kPartBuckets];
+  constexpr int kW = kNT / kWave;
+  __shared__ int32_t wcnt[kPartRounds * kW][kPartBuckets];  // [round][wavefront]: the order nodes appear in
   __shared__ int32_t base[kPartBuckets];
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)bx_ * kNT >= U) return;
+  if ((int64_t)bx_ * kPartSpan >= U) return;
   const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  for (int k = threadIdx.x; k < (kNT / kWave) * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < kPartRounds * kW * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
   if (threadIdx.x == 0) {
     int32_t acc = 0;
     for (int m = 0; m <= a.P; ++m) {  // concat order: parts[0..P-1] then cache hits
@@ -1157,40 +1170,51 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
       acc += s.st->pcnt[m];
     }
   }
+  int32_t b[kPartRounds], v[kPartRounds], rank_w[kPartRounds];
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    b[r] = i < U ? (int32_t)s.pbucket[i] : -1;
+    v[r] = i < U ? s.n_ids[i] : 0;
+  }
   __syncthreads();
-  const int32_t i = bx_ * kNT + threadIdx.x;
-  const bool valid = i < U;
-  const int32_t b = valid ? (int32_t)s.pbucket[i] : -1;
-  // stable rank inside the wavefront among lanes of the same bucket
-  int32_t rank_w = 0;
-  unsigned long long todo = __ballot(valid);
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int32_t lb = __shfl(b, leader, kWave);
-    const unsigned long long m = __ballot(valid && b == lb);
-    if (valid && b == lb) {
-      rank_w = __popcll(m & below);
-      if (lane == leader) wcnt[wid][lb] = __popcll(m);
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    // stable rank inside the wavefront among lanes of the same bucket
+    const bool valid = b[r] >= 0;
+    rank_w[r] = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int32_t lb = __shfl(b[r], leader, kWave);
+      const unsigned long long m = __ballot(valid && b[r] == lb);
+      if (valid && b[r] == lb) {
+        rank_w[r] = __popcll(m & below);
+        if (lane == leader) wcnt[r * kW + wid][lb] = __popcll(m);
+      }
+      todo &= ~m;
     }
-    todo &= ~m;
   }
   __syncthreads();
-  if (!valid) return;
-  int32_t pre = 0;
-  for (int w = 0; w < wid; ++w) pre += wcnt[w][b];
-  const int32_t v = s.n_ids[i];
-  const int32_t pos = base[b] + s.pblk[(int64_t)b * a.nblk_cap + bx_] + pre + rank_w;
-  s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
-  int32_t src_row;     // for the fused assembly (k_deliver): one record per node instead of pperm -> segment search -> id
-  if (b < a.P) {
-    s.parts[pos] = v;
-    src_row = (b == a.rank) ? (int32_t)((int64_t)v - a.off.v[a.rank]) : pos - base[b];
-  } else {
-    src_row = a.cache_map[v];  // nid2cachenid (:1256)
-    s.pcached[pos - base[a.P]] = src_row;
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    if (b[r] < 0) continue;
+    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    int32_t pre = 0;
+    for (int w = 0; w < r * kW + wid; ++w) pre += wcnt[w][b[r]];
+    const int32_t pos = base[b[r]] + s.pblk[(int64_t)b[r] * a.nblk_cap + bx_] + pre + rank_w[r];
+    s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
+    int32_t src_row;   // for the fused assembly (k_deliver): one record per node instead of pperm -> segment search -> id
+    if (b[r] < a.P) {
+      s.parts[pos] = v[r];
+      src_row = (b[r] == a.rank) ? (int32_t)((int64_t)v[r] - a.off.v[a.rank]) : pos - base[b[r]];
+    } else {
+      src_row = a.cache_map[v[r]];  // nid2cachenid (:1256)
+      s.pcached[pos - base[a.P]] = src_row;
+    }
+    s.psrc[i] = int2{b[r], src_row};
   }
-  s.psrc[i] = int2{b, src_row};
 }
 
 // ids requested from the peers, regrouped peer-major across the batches of a group (one send per
@@ -1939,7 +1963,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
   }
   if (s->part.P > 0) {
-    const unsigned gu = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[H], kNT));
+    const unsigned gu = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[H], kPartSpan));
     hipLaunchKernelGGL(k_gpart_hist, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
     hipLaunchKernelGGL(k_gpart_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), H, s->part);
     hipLaunchKernelGGL(k_gpart_scatter, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
