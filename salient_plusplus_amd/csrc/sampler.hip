@@ -355,36 +355,55 @@ __device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expect
   return last;
 }
 
+// One WAVEFRONT per 256 targets (the unit k_hop_pick's workgroups work in): four targets per lane, their
+// loads in flight together, and the unit's two sums by a wavefront reduction -- no LDS, no barrier.
 __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                     const int64_t* __restrict__ rowptr, int32_t h, int32_t f,
                                                     int32_t replace) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lds[2][kNT / kWave + 1];
+  constexpr int kPer = kNT / kWave;  // targets per lane
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
-  const int64_t i = (int64_t)bx_ * kNT + threadIdx.x;
-  if ((int64_t)bx_ * kNT >= T) return;
-  int32_t cnt = 0, smp = 0;
-  if (i < T) {
-    int32_t deg;
-    if (h > 0 && i < s.st->cnt[h - 1]) {
-      deg = s.deg[i];  // a target of the previous hop as well: its degree and row start are still in place
-    } else {
-      const int32_t v = s.n_ids[i];
-      const int64_t rs = rowptr[v];
-      const int64_t re = rowptr[v + 1];
-      deg = (int32_t)(re - rs);
-      s.deg[i] = deg;
-      s.rowstart[i] = rs;
-    }
-    target_counts(deg, f, replace, cnt, smp);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t unit = (int64_t)bx_ * (kNT / kWave) + threadIdx.x / kWave;  // index of the 256-target unit
+  const int64_t i0 = unit * kNT;
+  if (i0 >= T) return;
+  const int32_t Tprev = h > 0 ? s.st->cnt[h - 1] : 0;
+  int32_t v[kPer], deg[kPer];
+  int64_t rs[kPer], re[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int64_t i = i0 + u * kWave + lane;
+    // a target of the previous hop as well: its degree and row start are still in place
+    v[u] = (i < T && i >= Tprev) ? s.n_ids[i] : -1;
+    deg[u] = (i < T && i < Tprev) ? s.deg[i] : 0;
   }
-  int32_t tc, ts;
-  block_exclusive_scan<int32_t, kNT>(cnt, lds[0], &tc);
-  block_exclusive_scan<int32_t, kNT>(smp, lds[1], &ts);
-  if (threadIdx.x == 0) {
-    s.bsum0[bx_] = tc;
-    s.bsum1[bx_] = ts;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    rs[u] = v[u] >= 0 ? rowptr[v[u]] : 0;
+    re[u] = v[u] >= 0 ? rowptr[v[u] + 1] : 0;
+  }
+  int32_t cnt = 0, smp = 0;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int64_t i = i0 + u * kWave + lane;
+    if (v[u] >= 0) {
+      deg[u] = (int32_t)(re[u] - rs[u]);
+      s.deg[i] = deg[u];
+      s.rowstart[i] = rs[u];
+    }
+    if (i < T) {
+      int32_t c, m;
+      target_counts(deg[u], f, replace, c, m);
+      cnt += c;
+      smp += m;
+    }
+  }
+  cnt = wave_inclusive_scan(cnt);
+  smp = wave_inclusive_scan(smp);
+  if (lane == kWave - 1) {
+    s.bsum0[unit] = cnt;
+    s.bsum1[unit] = smp;
   }
 }
 
@@ -1882,7 +1901,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
     // per-lane row staging of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
-    if (h > 0) hipLaunchKernelGGL(k_hop_count, dim3((gt) * gy), dim3(kNT), 0, st, s->d_slots, GG(gt), rowptr, h, f, replace);
+    if (h > 0) {
+      const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
+      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, h, f, replace);
+    }
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
         s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(lead.ecap_dyn[h], 0x7fffffff);
