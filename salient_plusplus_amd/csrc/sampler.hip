@@ -275,6 +275,52 @@ __global__ __launch_bounds__(256) void k_narrow_col(const int64_t* __restrict__ 
     out[i] = (int32_t)col[i];
 }
 
+// Row stubs: one 128-byte, 128-byte-aligned record per node -- {degree, row start (lo, hi), the first 29
+// neighbours} -- built once per graph.  A sampled row's degree AND (for most rows) every neighbour the
+// picks can name then sit in ONE cache line at a computable address: k_hop_count / k_seed_init read the
+// header instead of a rowptr pair, k_hop_pick reads the line instead of an unaligned 128-byte piece of the
+// neighbour array (1.75 lines on average) -- only picks at positions >= 29 of longer rows still go to the
+// neighbour array.  14 GB for the 111 M-node graph (HBM is 288 GB); skipped when memory is short.
+constexpr int kStubInts = 32;
+constexpr int kStubNbr = kStubInts - 3;
+typedef int32_t stub4 __attribute__((ext_vector_type(4)));
+
+template <typename ColT>
+__global__ __launch_bounds__(256) void k_build_stubs(const int64_t* __restrict__ rowptr, const ColT* __restrict__ col,
+                                                     int64_t num_nodes, stub4* __restrict__ out) {
+  const int part = threadIdx.x & 7;
+  for (int64_t v = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); v < num_nodes; v += (int64_t)gridDim.x * 32) {
+    const int64_t rs = rowptr[v];
+    const int64_t d64 = rowptr[v + 1] - rs;
+    const int32_t deg = d64 > 0x7fffffff ? 0x7fffffff : (int32_t)d64;
+    int32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = part * 4 + k - 3;  // neighbour position held by this word (header words: negative)
+      e[k] = (idx >= 0 && idx < deg) ? (int32_t)col[rs + idx] : 0;
+    }
+    if (part == 0) {
+      e[0] = deg;
+      e[1] = (int32_t)(uint32_t)rs;
+      e[2] = (int32_t)(rs >> 32);
+    }
+    out[v * 8 + part] = stub4{e[0], e[1], e[2], e[3]};
+  }
+}
+
+// degree and row start of node v: from its stub's first 16 bytes, or from the rowptr pair
+__device__ __forceinline__ void row_header(const int64_t* __restrict__ rowptr, const stub4* __restrict__ stubs, int32_t v,
+                                           int32_t& deg, int64_t& rs) {
+  if (stubs) {
+    const stub4 hd = stubs[(int64_t)v * 8];
+    deg = hd.x;
+    rs = ((int64_t)hd.z << 32) | (uint32_t)hd.y;
+  } else {
+    rs = rowptr[v];
+    deg = (int32_t)(rowptr[v + 1] - rs);
+  }
+}
+
 __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t replace, int32_t& cnt, int32_t& smp) {
   if (replace && f >= 0) {
     // with replacement (sample_cpu.hpp:74-82): f draws of gen() % deg whenever deg > 0
@@ -293,7 +339,8 @@ __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t re
 // Also the degree pass of hop 0 (k_hop_count with h = 0: the targets are the seeds themselves), so a
 // chain starts with one launch instead of two.
 __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g,
-                                                    const int64_t* __restrict__ rowptr, int32_t f, int32_t replace) {
+                                                    const int64_t* __restrict__ rowptr,
+                                                    const stub4* __restrict__ stubs, int32_t f, int32_t replace) {
   SPP_GROUP_BLOCK(ga.grid);
   __shared__ int32_t lds[2][kNT / kWave + 1];
   const SlotPtrs& s = slots[ga.first_slot + by_];
@@ -310,14 +357,14 @@ __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ 
   int32_t cnt = 0, smp = 0;
   if (i < n_seeds) {
     const int32_t v = (int32_t)seeds[i];  // narrowing of fast_sampler.cpp:196-199
-    const int64_t rs = rowptr[v];
-    const int64_t re = rowptr[v + 1];
+    int32_t deg;
+    int64_t rs;
+    row_header(rowptr, stubs, v, deg, rs);
     s.n_ids[i] = v;
     const uint32_t b = bucket_of((uint32_t)v, g.nb_log2);
     const int32_t j = atomicAdd(&s.kcount[b], 1);
     if (j < g.kcap) s.known[(int64_t)b * g.kcap + j] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)i;
     else atomicOr(&s.st->error, kErrBucketCap);
-    const int32_t deg = (int32_t)(re - rs);
     s.deg[i] = deg;
     s.rowstart[i] = rs;
     target_counts(deg, f, replace, cnt, smp);
@@ -358,7 +405,8 @@ __device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expect
 // One WAVEFRONT per 256 targets (the unit k_hop_pick's workgroups work in): four targets per lane, their
 // loads in flight together, and the unit's two sums by a wavefront reduction -- no LDS, no barrier.
 __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                    const int64_t* __restrict__ rowptr, int32_t h, int32_t f,
+                                                    const int64_t* __restrict__ rowptr,
+                                                    const stub4* __restrict__ stubs, int32_t h, int32_t f,
                                                     int32_t replace) {
   SPP_GROUP_BLOCK(gg);
   constexpr int kPer = kNT / kWave;  // targets per lane
@@ -370,7 +418,7 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
   if (i0 >= T) return;
   const int32_t Tprev = h > 0 ? s.st->cnt[h - 1] : 0;
   int32_t v[kPer], deg[kPer];
-  int64_t rs[kPer], re[kPer];
+  int64_t rs[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int64_t i = i0 + u * kWave + lane;
@@ -378,17 +426,19 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
     v[u] = (i < T && i >= Tprev) ? s.n_ids[i] : -1;
     deg[u] = (i < T && i < Tprev) ? s.deg[i] : 0;
   }
+  int32_t nd[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
-    rs[u] = v[u] >= 0 ? rowptr[v[u]] : 0;
-    re[u] = v[u] >= 0 ? rowptr[v[u] + 1] : 0;
+    nd[u] = 0;
+    rs[u] = 0;
+    if (v[u] >= 0) row_header(rowptr, stubs, v[u], nd[u], rs[u]);
   }
   int32_t cnt = 0, smp = 0;
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int64_t i = i0 + u * kWave + lane;
     if (v[u] >= 0) {
-      deg[u] = (int32_t)(re[u] - rs[u]);
+      deg[u] = nd[u];
       s.deg[i] = deg[u];
       s.rowstart[i] = rs[u];
     }
@@ -443,9 +493,10 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
 // ----------------------------------------------------------------------------------------------
-template <bool kGeneric, typename ColT>
+template <bool kGeneric, typename ColT, bool kStub>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                   const ColT* __restrict__ col, int32_t h, int32_t f,
+                                                   const ColT* __restrict__ col, const stub4* __restrict__ stubs,
+                                                   int32_t h, int32_t f,
                                                    int32_t replace, int32_t self_prefix, int32_t ecap, int64_t dcap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
@@ -467,24 +518,35 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   // Cooperative neighbour reads, issued FIRST: they need only the rows' starts and lengths, not the
   // picks, so the one long HBM miss of this kernel overlaps the offset sums, the draws and the Floyd steps.
   // One lane fetching its own picks would issue `cnt` scattered 4-byte loads -- `cnt` cache-line requests
-  // for a row that spans one or two lines.  Instead 8 lanes read the first 32 neighbours of a row as one
+  // for a row that spans one or two lines.  Instead 8 lanes read the row's first neighbours as one
   // contiguous 128-byte request: 8 rows per wavefront load instruction, 8 rounds for the wavefront's 64
-  // rows.  (Rows are read even when a capacity error will discard them: harmless.)
-  constexpr int kSeg = 32;
+  // rows.  With row stubs (kStub) the request is the node's stub -- one aligned line holding the first 29
+  // neighbours after a 3-word header; without, the first 32 entries of the row in the int32 neighbour
+  // array (unaligned: 1.75 lines on average).  (Rows are read even when a capacity error will discard
+  // them: harmless.)
+  constexpr int kSeg = kStub ? kStubNbr : 32;   // neighbour positions served from the staged line
+  constexpr int kSegOff = kStub ? 3 : 0;        // word of the staged line holding position 0
   typedef int32_t i4 __attribute__((ext_vector_type(4)));
   typedef int32_t i4u __attribute__((ext_vector_type(4), aligned(4)));
-  constexpr bool kCoop = !kGeneric && sizeof(ColT) == 4;
+  constexpr bool kCoop = !kGeneric && (kStub || sizeof(ColT) == 4);
   i4 seg[kCoop ? 8 : 1];
   if constexpr (kCoop) {
     const int lane = threadIdx.x & (kWave - 1), j = lane >> 3, part = lane & 7;
-    const int32_t seglen = deg < kSeg ? deg : kSeg;  // 0 for lanes without a target
+    const int32_t seglen = (deg < kSeg ? deg : kSeg) + (deg > 0 ? kSegOff : 0);  // words wanted; 0 for lanes without a target
+    int32_t vnode = 0;
+    if constexpr (kStub) vnode = (i < T) ? s.n_ids[i] : 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int src = r * 8 + j;
-      const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
-                           (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
       const int32_t len_r = __shfl(seglen, src, kWave);
-      seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
+      if constexpr (kStub) {
+        const int32_t v_r = __shfl(vnode, src, kWave);
+        seg[r] = (part * 4 < len_r) ? stubs[(int64_t)v_r * 8 + part] : i4{0, 0, 0, 0};
+      } else {
+        const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
+                             (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
+        seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
+      }
     }
   }
   // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
@@ -576,7 +638,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   if constexpr (kCoop) {
     // The rows fetched at the top pass through a 1 KB LDS stage per wavefront, and each lane takes its
     // picks from there.  Picks at positions >= 32 (rows of higher degree) are read directly.
-    __shared__ i4 stage[kNT / kWave][8][kSeg / 4 + 1];  // +1: rows start in different LDS banks
+    __shared__ i4 stage[kNT / kWave][8][8 + 1];  // +1: rows start in different LDS banks
     const int lane = tid & (kWave - 1), wid = tid / kWave, j = lane >> 3, part = lane & 7;
     // far picks (position >= kSeg): direct reads, batched; the neighbour id replaces the position as ~id
     for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
@@ -601,8 +663,9 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       if ((lane >> 3) == r) {
         const int32_t* row = reinterpret_cast<const int32_t*>(&stage[wid][lane & 7][0]);
         for (int32_t k = 0; k < cnt; ++k) {
-          const int32_t c = smp ? chosen[k][tid] : k;
-          chosen[k][tid] = c >= 0 ? row[c] : ~c;  // now the neighbour id
+          // unsampled rows take every position in order; positions past the staged line were fetched above
+          const int32_t c = (smp || k >= kSeg) ? chosen[k][tid] : k;
+          chosen[k][tid] = c >= 0 ? row[c + kSegOff] : ~c;  // now the neighbour id
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1363,6 +1426,19 @@ struct Col32 {
 static std::mutex g_col32_mu;
 static std::map<std::tuple<const void*, int64_t, int>, std::weak_ptr<Col32>> g_col32;
 
+// row stubs of a graph (k_build_stubs), shared like the int32 neighbour array
+struct RowStubs {
+  stub4* p = nullptr;
+  int device = 0;
+  ~RowStubs() {
+    if (p) {
+      (void)hipSetDevice(device);
+      (void)hipFree(p);
+    }
+  }
+};
+static std::map<std::tuple<const void*, const void*, int64_t, int>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
+
 struct SlotHost {
   SlotPtrs p{};
   hipEvent_t done = nullptr;        // own event object
@@ -1402,6 +1478,8 @@ struct spp_sampler {
   int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
   std::shared_ptr<Col32> col32_owner;  // int32 copy of cfg.col_dev, shared by the samplers of one graph
   int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
+  std::shared_ptr<RowStubs> stubs_owner;
+  const stub4* stubs = nullptr;      // = stubs_owner->p (NULL: degree from rowptr, neighbours from the array only)
   // epoch arena of mt19937 streams (sampler_rng_arena): one stream per batch of the current range table
   uint32_t* rng_arena = nullptr;
   int64_t rng_arena_words = 0;       // allocated size
@@ -1640,6 +1718,49 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       }
     }
   }
+  // Row stubs (128 B per node): SPP_ROW_STUBS=0 off, =1 always; default: when they take at most a quarter
+  // of the memory that is free right now (the caller may still have tensors to place).  Only the fast path
+  // uses them.
+  if (rc == SPP_OK && cfg->nnz > 0 && cfg->num_nodes > 0 && !s->any_generic) {
+    const char* e = getenv("SPP_ROW_STUBS");
+    const int mode = e ? atoi(e) : -1;
+    const size_t need = sizeof(int32_t) * kStubInts * (size_t)cfg->num_nodes;
+    std::lock_guard<std::mutex> lk(g_col32_mu);
+    const auto key = std::make_tuple((const void*)cfg->rowptr_dev, (const void*)cfg->col_dev, cfg->nnz, (int)cfg->device);
+    std::shared_ptr<RowStubs> c = g_stubs[key].lock();
+    if (!c && mode != 0) {
+      size_t free_b = 0, total_b = 0;
+      const bool room = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4);
+      if (room) {
+        c = std::make_shared<RowStubs>();
+        c->device = cfg->device;
+        if (hipMalloc((void**)&c->p, need) != hipSuccess) {
+          (void)hipGetLastError();
+          c->p = nullptr;
+          c.reset();  // no stubs: not an error
+        } else {
+          const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(cfg->num_nodes, 32), 256 * 64);
+          if (s->col32)
+            hipLaunchKernelGGL(k_build_stubs<int32_t>, dim3(grid), dim3(256), 0, nullptr, cfg->rowptr_dev, s->col32,
+                               cfg->num_nodes, c->p);
+          else
+            hipLaunchKernelGGL(k_build_stubs<int64_t>, dim3(grid), dim3(256), 0, nullptr, cfg->rowptr_dev, cfg->col_dev,
+                               cfg->num_nodes, c->p);
+          if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            set_error("spp_sampler_create: building the row stubs failed");
+            rc = SPP_ERR_HIP;
+          } else {
+            g_stubs[key] = c;
+          }
+        }
+      }
+    }
+    if (rc == SPP_OK && c && c->p) {
+      s->stubs_owner = c;
+      s->stubs = c->p;
+      s->bytes += (int64_t)need;
+    }
+  }
   if (rc == SPP_OK) {
     // k_bucket_scatter stages a tile in up to 80 KB of dynamic LDS (gfx950: 160 KB per CU and per workgroup)
     const int need = (int)(sizeof(int32_t) * 2 * kMaxBuckets + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
@@ -1868,6 +1989,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const int64_t* rowptr = s->cfg.rowptr_dev;
   const int64_t* col = s->cfg.col_dev;
   const int32_t* col32 = s->col32;
+  const stub4* stubs = s->stubs;
   const int32_t replace = s->cfg.replace ? 1 : 0;
   GroupArgs ga{};
   ga.first_slot = first_slot;
@@ -1894,7 +2016,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
   const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
   ga.grid = GG(gseed);
-  hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom, rowptr,
+  hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom, rowptr, stubs,
                      (int32_t)s->cfg.sizes[0], replace);  // includes hop 0's degree pass
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
@@ -1903,7 +2025,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
     if (h > 0) {
       const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
-      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, h, f, replace);
+      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, h, f, replace);
     }
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
@@ -1915,12 +2037,18 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     unsigned ge;
     if (!s->generic[h]) {
-      if (col32)
-        hipLaunchKernelGGL((k_hop_pick<false, int32_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, h, f, replace, self_prefix, ecap_dev, s->dcap);
+      if (col32 && stubs)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+      else if (col32)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+      else if (stubs)
+        hipLaunchKernelGGL((k_hop_pick<false, int64_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
       else
-        hipLaunchKernelGGL((k_hop_pick<false, int64_t>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, h, f, replace, self_prefix, ecap_dev, s->dcap);
+        hipLaunchKernelGGL((k_hop_pick<false, int64_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -1930,8 +2058,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       if (lead.host_state->error) break;
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
-      hipLaunchKernelGGL((k_hop_pick<true, int64_t>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
-                         GG(gt), col, h, f, replace, 0, ecap_dev, s->dcap);
+      hipLaunchKernelGGL((k_hop_pick<true, int64_t, false>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
+                         GG(gt), col, stubs, h, f, replace, 0, ecap_dev, s->dcap);
       if (col32)
         hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col32,
                            h, f, replace);

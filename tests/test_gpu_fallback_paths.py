@@ -3,7 +3,9 @@ one.  Each case runs in a fresh interpreter (the knobs are read once per process
 of a short epoch with the oracle:
   * SPP_RNG_ARENA_MB=0   -- no epoch arena: mt19937 streams generated per group into the slots' ping-pong buffers;
   * SPP_XCD_AFFINITY=0   -- batch-major instead of batch-interleaved workgroup ids;
-  * SPP_COL32=0          -- the int64 neighbour array (no cooperative row reads);
+  * SPP_COL32=0          -- the int64 neighbour array (picks at positions >= 29 read it; the row stubs still serve the rest);
+  * SPP_ROW_STUBS=0      -- no row stubs: degrees from rowptr, cooperative reads of the int32 neighbour array;
+  * both off             -- lane-private reads of the int64 array;
   * SPP_GROUP_SIZE=3     -- ragged groups, slot-sets of 3;
   * SPP_DEDUP_BUCKET=64  -- many small dedup buckets (coarse/fine bucket runs, 2^11-slot LDS tables)."""
 import os
@@ -56,6 +58,8 @@ print("CHILD_OK", n)
     {"SPP_RNG_ARENA_MB": "0"},
     {"SPP_XCD_AFFINITY": "0"},
     {"SPP_COL32": "0"},
+    {"SPP_ROW_STUBS": "0"},
+    {"SPP_ROW_STUBS": "0", "SPP_COL32": "0"},
     {"SPP_GROUP_SIZE": "3"},
     {"SPP_DEDUP_BUCKET": "64"},
     {"SPP_RNG_ARENA_MB": "0", "SPP_GROUP_SIZE": "5", "SPP_XCD_AFFINITY": "0"},
