@@ -72,6 +72,10 @@ __device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t 
   const int gpb = kGatherThreads >> lpr_log2;  // row groups per workgroup
   const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
   for (int64_t base = vblock * rows_per_iter; base < n; base += nvblocks * rows_per_iter) {
+    // Branch-free loads: a row index past the end is clamped to the last row (loaded, never stored).  With
+    // `if (ok) v = load` the compiler put every load in its own exec-masked block behind an
+    // s_waitcnt vmcnt(0) -- ONE load in flight per wavefront whatever the unroll; now the kGatherUnroll
+    // index loads, then the kGatherUnroll row loads, are issued back to back.
     const V* s[kGatherUnroll];
     V* d[kGatherUnroll];
     bool ok[kGatherUnroll];
@@ -79,14 +83,13 @@ __device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t 
     for (int u = 0; u < kGatherUnroll; ++u) {
       const int64_t r = base + (int64_t)u * gpb + g;
       ok[u] = r < n;
-      s[u] = reinterpret_cast<const V*>(src_of(ok[u] ? r : 0));
+      s[u] = reinterpret_cast<const V*>(src_of(ok[u] ? r : n - 1));
       d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
     }
     for (int c = l; c < chunks; c += lpr) {
       V v[kGatherUnroll];
 #pragma unroll
-      for (int u = 0; u < kGatherUnroll; ++u)
-        if (ok[u]) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
+      for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u)
         if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);

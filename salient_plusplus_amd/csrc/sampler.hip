@@ -118,6 +118,20 @@ struct GroupGrid {
   }                                                 \
   (void)bx_
 
+// Pointers that reach a kernel through SlotPtrs (loaded from memory) are generic to the compiler: it emits
+// FLAT loads, which count on the LDS counter as well -- every wait for an LDS operation or a wavefront
+// shuffle then also waits for every global load in flight.  G() names the address space, so that the hot
+// kernels get global_load/global_store and their loads stay in flight across LDS work.
+#define SPP_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ SPP_GLOBAL T* G(T* p) {
+  return (SPP_GLOBAL T*)p;
+}
+template <typename T>
+__device__ __forceinline__ const SPP_GLOBAL T* G(const T* p) {
+  return (const SPP_GLOBAL T*)p;
+}
+
 // device-resident bookkeeping of one batch slot (copied to pinned host memory after sampling)
 struct SlotState {
   int32_t cnt[SPP_MAX_HOPS + 1];   // cnt[0] = #seeds, cnt[h+1] = #nodes after hop h (processing order)
@@ -497,7 +511,8 @@ template <bool kGeneric, typename ColT, bool kStub>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                    const ColT* __restrict__ col, const stub4* __restrict__ stubs,
                                                    int32_t h, int32_t f,
-                                                   int32_t replace, int32_t self_prefix, int32_t ecap, int64_t dcap) {
+                                                   int32_t replace, int32_t self_prefix, int32_t ecap, int64_t dcap,
+                                                   int32_t tcap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   // Floyd picks of the row, one column per lane: f rows of kNT ints, sized by the launch (dynamic LDS) --
@@ -505,18 +520,46 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   extern __shared__ int32_t chosen_lds[];
   int32_t (*chosen)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(chosen_lds);
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t T = s.st->cnt[h];
-  if ((int64_t)bx_ * kNT >= T && bx_ != 0) return;  // workgroup 0 always runs: it records the totals of an empty hop
+  SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* bsum0 = G(s.bsum0);
+  const SPP_GLOBAL int32_t* bsum1 = G(s.bsum1);
+  SPP_GLOBAL int32_t* out_rp = G(s.out_rowptr[h]);
   const int32_t i = bx_ * kNT + threadIdx.x;
-  int32_t deg = 0, cnt = 0, smp = 0;
-  int64_t rs = 0;
-  if (i < T) {
-    deg = s.deg[i];
-    rs = s.rowstart[i];
-    target_counts(deg, f, replace, cnt, smp);
+  // ---- round trip 1: everything that does not depend on another load of this kernel, issued together.
+  // The per-target arrays are read at a clamped index before T is known (they are sized for tcap).
+  const int32_t ic = i < tcap ? i : tcap - 1;
+  const int32_t T = st->cnt[h];
+  const int32_t err0 = st->error;
+  const int64_t dbase = st->dbase[h];
+  const uint32_t* rng_gen = st->rng;
+  int32_t deg = G(s.deg)[ic];
+  int64_t rs = G(s.rowstart)[ic];
+  int32_t vnode = kStub ? G(s.n_ids)[ic] : 0;
+  // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
+  // workgroup adds up their per-workgroup sums (k_hop_count) itself -- at most a few loads per lane --
+  // instead of a single-workgroup scan kernel between the two launches; the last workgroup records the
+  // hop's totals.  (Without: bsum0/bsum1 were scanned in place by k_hop_scan.)
+  int32_t a0 = 0, a1 = 0;
+  if (self_prefix) {
+    for (int k = threadIdx.x; k < (int)bx_; k += kNT) {
+      a0 += bsum0[k];
+      a1 += bsum1[k];
+    }
+  } else {
+    a0 = bsum0[bx_];
+    a1 = bsum1[bx_];
   }
-  // Cooperative neighbour reads, issued FIRST: they need only the rows' starts and lengths, not the
-  // picks, so the one long HBM miss of this kernel overlaps the offset sums, the draws and the Floyd steps.
+  if ((int64_t)bx_ * kNT >= T && bx_ != 0) return;  // workgroup 0 always runs: it records the totals of an empty hop
+  int32_t cnt = 0, smp = 0;
+  if (i < T) {
+    target_counts(deg, f, replace, cnt, smp);
+  } else {
+    deg = 0;
+    rs = 0;
+    vnode = 0;
+  }
+  // ---- round trip 2.  Cooperative neighbour reads: they need only the rows' nodes / starts and lengths,
+  // not the picks, so the one long HBM miss of this kernel overlaps the offset sums, the draws and the Floyd steps.
   // One lane fetching its own picks would issue `cnt` scattered 4-byte loads -- `cnt` cache-line requests
   // for a row that spans one or two lines.  Instead 8 lanes read the row's first neighbours as one
   // contiguous 128-byte request: 8 rows per wavefront load instruction, 8 rounds for the wavefront's 64
@@ -533,15 +576,15 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   if constexpr (kCoop) {
     const int lane = threadIdx.x & (kWave - 1), j = lane >> 3, part = lane & 7;
     const int32_t seglen = (deg < kSeg ? deg : kSeg) + (deg > 0 ? kSegOff : 0);  // words wanted; 0 for lanes without a target
-    int32_t vnode = 0;
-    if constexpr (kStub) vnode = (i < T) ? s.n_ids[i] : 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int src = r * 8 + j;
       const int32_t len_r = __shfl(seglen, src, kWave);
       if constexpr (kStub) {
+        // unconditional (lanes without a target read node 0's stub): a stub is ONE line whatever the row's
+        // length, and a conditional load made the compiler wait for each load before issuing the next
         const int32_t v_r = __shfl(vnode, src, kWave);
-        seg[r] = (part * 4 < len_r) ? stubs[(int64_t)v_r * 8 + part] : i4{0, 0, 0, 0};
+        seg[r] = stubs[(int64_t)v_r * 8 + part];
       } else {
         const int64_t rs_r = ((int64_t)__shfl((int32_t)(rs >> 32), src, kWave) << 32) |
                              (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
@@ -549,47 +592,38 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
     }
   }
-  // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
-  // workgroup adds up their per-workgroup sums (k_hop_count) itself -- at most a few loads per lane --
-  // instead of a single-workgroup scan kernel between the two launches; the last workgroup records the
-  // hop's totals.  (Without: bsum0/bsum1 were scanned in place by k_hop_scan.)
   int32_t pre0, pre1, tot0, tot1;
   if (self_prefix) {
-    int32_t a0 = 0, a1 = 0;
-    for (int k = threadIdx.x; k < (int)bx_; k += kNT) {
-      a0 += s.bsum0[k];
-      a1 += s.bsum1[k];
-    }
     block_exclusive_scan<int32_t, kNT>(a0, lds_scan[0], &pre0);
     block_exclusive_scan<int32_t, kNT>(a1, lds_scan[1], &pre1);
     __syncthreads();  // lds_scan is reused below
   } else {
-    pre0 = s.bsum0[bx_];
-    pre1 = s.bsum1[bx_];
+    pre0 = a0;
+    pre1 = a1;
   }
   const int32_t p0 = pre0 + block_exclusive_scan<int32_t, kNT>(cnt, lds_scan[0], &tot0);
   const int32_t r0 = pre1 + block_exclusive_scan<int32_t, kNT>(smp, lds_scan[1], &tot1);
   if (self_prefix && threadIdx.x == 0 && (int64_t)(bx_ + 1) * kNT >= T) {  // the last workgroup with targets
     const int32_t E = pre0 + tot0, S = pre1 + tot1;
-    s.st->E[h] = E;
-    s.st->nsmp[h] = S;
-    s.out_rowptr[h][T] = E;
+    st->E[h] = E;
+    st->nsmp[h] = S;
+    out_rp[T] = E;
     if (E > ecap) atomicOr(&s.st->error, kErrEdgeCap);
-    if (s.st->dbase[h] + (int64_t)(f > 0 ? f : 0) * S > dcap) atomicOr(&s.st->error, kErrDrawCap);
+    if (dbase + (int64_t)(f > 0 ? f : 0) * S > dcap) atomicOr(&s.st->error, kErrDrawCap);
   }
   // lanes without a target (or past a capacity error) stay until the end: the cooperative row reads
   // below use whole wavefronts
   bool live = i < T;
-  if (live && self_prefix && (p0 + cnt > ecap || (smp && s.st->dbase[h] + (int64_t)f * (r0 + 1) > dcap))) live = false;
-  if (live) s.out_rowptr[h][i] = p0;
-  if (s.st->error) live = false;
+  if (live && self_prefix && (p0 + cnt > ecap || (smp && dbase + (int64_t)f * (r0 + 1) > dcap))) live = false;
+  if (live) out_rp[i] = p0;
+  if (err0) live = false;  // an earlier kernel of the chain failed: nothing to do
   if (!live) {
     cnt = 0;
     smp = 0;
     deg = 0;
   }
-  const uint32_t* rng = s.st->rng;
-  if (smp) rng += s.st->dbase[h] + (int64_t)f * r0;
+  const SPP_GLOBAL uint32_t* rng = G(rng_gen);
+  if (smp) rng += dbase + (int64_t)f * r0;
   if (kGeneric) {
     // only the Floyd picks are produced here (into evals[p0..p0+f), free at this point);
     // expansion is edge-parallel
@@ -618,7 +652,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     for (int32_t k0 = 0; k0 < f; k0 += 8) {
       uint32_t r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = (k0 + u < f) ? rng[k0 + u] : 0u;
+      for (int u = 0; u < 8; ++u) r[u] = rng[k0 + u < f ? k0 + u : f - 1];  // clamped, not predicated: the 8 loads issue back to back
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int32_t k = k0 + u;
@@ -649,7 +683,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
         const int32_t k = k0 + u;
         const int32_t w = (k < cnt) ? (smp ? chosen[k][tid] : k) : 0;
         far[u] = k < cnt && w >= kSeg;
-        nb[u] = far[u] ? (int32_t)col[rs + w] : 0;
+        nb[u] = (int32_t)col[far[u] ? rs + w : 0];  // not predicated: lanes without a far pick share col[0]'s line
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -671,7 +705,8 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    for (int32_t k = 0; k < cnt; ++k) s.cval[p0 + k] = chosen[k][tid];
+    SPP_GLOBAL int32_t* cv = G(s.cval) + p0;
+    for (int32_t k = 0; k < cnt; ++k) cv[k] = chosen[k][tid];
   } else {
     // neighbour reads in batches of 8 held in registers: the loads of a batch are all issued before the
     // first use, so a lane has up to 8 independent HBM misses in flight instead of one per iteration
@@ -684,7 +719,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (k0 + u < cnt) s.cval[p0 + k0 + u] = nb[u];
+        if (k0 + u < cnt) G(s.cval)[p0 + k0 + u] = nb[u];
     }
   }
 }
@@ -2039,16 +2074,16 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     if (!s->generic[h]) {
       if (col32 && stubs)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
       else if (col32)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
       else if (stubs)
         hipLaunchKernelGGL((k_hop_pick<false, int64_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
       else
         hipLaunchKernelGGL((k_hop_pick<false, int64_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap);
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -2059,7 +2094,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
       hipLaunchKernelGGL((k_hop_pick<true, int64_t, false>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
-                         GG(gt), col, stubs, h, f, replace, 0, ecap_dev, s->dcap);
+                         GG(gt), col, stubs, h, f, replace, 0, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
       if (col32)
         hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col32,
                            h, f, replace);

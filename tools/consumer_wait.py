@@ -41,12 +41,21 @@ for rep in range(2):
     torch.cuda.synchronize()
     b0 = sess.total_blocked_dur.total_seconds()
     o0 = sess.total_blocked_occasions
+    prof = None
+    if os.environ.get("PROFILE") == "1" and rep == 1:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     n = 0
     for _ in dp:
         n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof).sort_stats("tottime").print_stats(22)
     blocked = sess.total_blocked_dur.total_seconds() - b0
     occ = sess.total_blocked_occasions - o0
     print(f"rep {rep}: {n} batches, {dt / n * 1e6:.1f} us per batch wall; consumer blocked waiting for sampling "
