@@ -150,6 +150,17 @@ struct __attribute__((aligned(16))) RankWord {
   uint32_t pad;
 };
 
+// a rank record through a global-address-space pointer (one 16-byte load)
+typedef uint32_t rw_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ RankWord load_rank_word(const SPP_GLOBAL RankWord* p, uint32_t w) {
+  const rw_u4 v = reinterpret_cast<const SPP_GLOBAL rw_u4*>(p)[w];
+  RankWord r;
+  r.bits = ((unsigned long long)v.y << 32) | v.x;
+  r.pre = v.z;
+  r.pad = 0u;
+  return r;
+}
+
 struct SlotPtrs {
   int32_t* n_ids;
   int32_t* deg;
@@ -904,7 +915,13 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   __shared__ int ovf;
   constexpr uint32_t mask = (1u << LDS_LOG2) - 1;
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  if (s.st->error) return;
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL unsigned long long* bpairs = G(s.bpairs);
+  SPP_GLOBAL unsigned long long* known = G(s.known);
+  SPP_GLOBAL int32_t* kcount = G(s.kcount);
+  const SPP_GLOBAL RankWord* fwords = G(s.fwords);
+  const SPP_GLOBAL int32_t* fsum = G(s.fsum);
+  SPP_GLOBAL uint32_t* res = G(s.res);
   // A hop's bucket is a run of 2^shift consecutive fine buckets (bucket ids are top bits of one hash):
   // small hops use few, well-filled workgroups instead of thousands that each set up an LDS table
   // for a handful of edges; the known-node lists stay per FINE bucket for the later, larger hops.
@@ -912,23 +929,26 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   const int32_t shift = g.nb_log2 - cb_log2;
   const int32_t nf = 1 << shift;
   const int32_t fb0 = b << shift;
-  const uint32_t T = (uint32_t)s.st->cnt[h];
-  const uint32_t Tprev = h > 0 ? (uint32_t)s.st->cnt[h - 1] : 0u;
-  const int32_t e0 = s.boff[b], e1 = s.boff[b + 1];
+  // ---- round trip 1: the state words, the bucket's bounds and the fine lists' lengths, issued together
+  const int32_t err0 = st->error;
+  const uint32_t T = (uint32_t)st->cnt[h];
+  const uint32_t Tprev = h > 0 ? (uint32_t)st->cnt[h - 1] : 0u;
+  const int32_t e0 = G(s.boff)[b], e1 = G(s.boff)[b + 1];
+  for (int i = threadIdx.x; i < nf; i += kNT) {
+    fkc[i] = kcount[fb0 + i];
+    fnew[i] = 0;
+  }
+  if (err0) return;
   const bool work = e1 > e0;  // block-uniform
-  // this hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in registers between the
-  // insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them).  Their loads are
-  // issued FIRST: they depend on nothing but the bucket's bounds, and the known-list phase (two more
-  // dependent global round trips) runs while they are in flight.
+  // ---- round trip 2.  This hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in
+  // registers between the insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them).
+  // Index clamped instead of a predicated load, so that the loads issue back to back.
   unsigned long long pr[kDedupRegs];
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u) {
     const int i = e0 + u * kNT + threadIdx.x;
-    pr[u] = (work && i < e1) ? s.bpairs[i] : kEmptySlot;
-  }
-  for (int i = threadIdx.x; i < nf; i += kNT) {
-    fkc[i] = s.kcount[fb0 + i];
-    fnew[i] = 0;
+    const unsigned long long v = bpairs[i < e1 ? i : 0];  // (an empty bucket has e1 == e0 <= i)
+    pr[u] = i < e1 ? v : kEmptySlot;
   }
   if (work)
     for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
@@ -939,27 +959,33 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   // one wavefront per fine list
   const int lane = threadIdx.x & (kWave - 1);
   for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
-    unsigned long long* kl = s.known + (int64_t)(fb0 + lf) * g.kcap;
+    SPP_GLOBAL unsigned long long* kl = known + (int64_t)(fb0 + lf) * g.kcap;
     const int32_t kc = fkc[lf];
     for (int i0 = lane; i0 < kc; i0 += 4 * kWave) {  // 4 entries per lane and round, loads batched
       unsigned long long e[4];
-      int32_t rk[4];
+      uint32_t q[4];
+      RankWord rw[4];
+      int32_t fs[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * kWave;
-        e[u] = i < kc ? kl[i] : kEmptySlot;
+        const unsigned long long v = kl[i < kc ? i : 0];  // kc > 0 here
+        e[u] = i < kc ? v : kEmptySlot;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u) {  // rank records of the pending entries (others read record 0: no branch)
         const uint32_t val = (uint32_t)e[u];
-        rk[u] = (e[u] != kEmptySlot && (val & kPending)) ? first_rank(s, val & ~kPending) : -1;
+        const bool pend = e[u] != kEmptySlot && (val & kPending);
+        q[u] = pend ? (val & ~kPending) : 0u;
+        rw[u] = load_rank_word(fwords, q[u] >> 6);
+        fs[u] = fsum[q[u] >> 8];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (e[u] == kEmptySlot) continue;
         uint32_t val = (uint32_t)e[u];
-        if (rk[u] >= 0) {
-          val = Tprev + (uint32_t)rk[u];
+        if (val & kPending) {
+          val = Tprev + (uint32_t)(fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull)));
           e[u] = (e[u] & 0xffffffff00000000ull) | val;
           kl[i0 + u * kWave] = e[u];
         }
@@ -977,7 +1003,8 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * kNT;
-      q[u] = i < e1 ? s.bpairs[i] : kEmptySlot;
+      const unsigned long long v = bpairs[i < e1 ? i : e0];
+      q[u] = i < e1 ? v : kEmptySlot;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -991,23 +1018,23 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   auto resolve = [&](unsigned long long pair, int i) {
     const uint32_t key = (uint32_t)(pair >> 32), p = (uint32_t)pair;
     const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
-    s.res[i] = val;  // bucket order: consecutive lanes, consecutive words (k_hop_flag brings it to position order)
+    res[i] = val;  // bucket order: consecutive lanes, consecutive words (k_hop_flag brings it to position order)
     if (val == T + p && !last_hop) {  // first occurrence of a new node: append to its fine list (no later hop: skip)
       const int32_t lf = (int32_t)bucket_of(key, g.nb_log2) - fb0;
       const int j = fkc[lf] + atomicAdd(&fnew[lf], 1);
-      if (j < g.kcap) s.known[(int64_t)(fb0 + lf) * g.kcap + j] = ((unsigned long long)key << 32) | kPending | p;
+      if (j < g.kcap) known[(int64_t)(fb0 + lf) * g.kcap + j] = ((unsigned long long)key << 32) | kPending | p;
       else ovf = 1;
     }
   };
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u)
     if (pr[u] != kEmptySlot) resolve(pr[u], e0 + u * kNT + threadIdx.x);
-  for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(s.bpairs[i], i);
+  for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(bpairs[i], i);
   __syncthreads();
   if (threadIdx.x == 0 && ovf) atomicOr(&s.st->error, kErrBucketCap);
   for (int i = threadIdx.x; i < nf; i += kNT) {
     const int32_t room = g.kcap - fkc[i];
-    s.kcount[fb0 + i] = fkc[i] + (fnew[i] < room ? fnew[i] : room);
+    kcount[fb0 + i] = fkc[i] + (fnew[i] < room ? fnew[i] : room);
   }
 }
 
