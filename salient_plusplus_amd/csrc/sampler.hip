@@ -1069,37 +1069,43 @@ __device__ int32_t scan_block_sums_acquire(int32_t* a, int32_t n, int32_t* lds) 
 // counts.  The workgroup that finishes last (device-scope ticket) turns the block counts into the
 // exclusive prefix and records the hop's node count -- no separate scan launch.
 __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                       int32_t f, int32_t ucap) {
+                                                       int32_t f, int32_t ucap, int64_t pcap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t wcnt[kFlagRounds][kFlagNT / kWave];
   __shared__ int32_t lscan[kFlagNT / kWave + 1];
   __shared__ int is_last;
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  SlotState* st = s.st;
-  if (st->error) {
-    if (bx_ == 0 && threadIdx.x == 0) {  // keep the later hops' sizes defined
-      st->cnt[h + 1] = st->cnt[h];
-      st->dbase[h + 1] = st->dbase[h];
-    }
-    return;
-  }
-  const int32_t E = st->E[h];
-  const int32_t nwg = E > 0 ? (E + kFlagSpan - 1) / kFlagSpan : 1;  // workgroup 0 always takes part
-  if ((int32_t)bx_ >= nwg) return;
-  const uint32_t T = (uint32_t)st->cnt[h];
+  SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL uint32_t* inv = G(s.inv);
+  const SPP_GLOBAL uint32_t* res = G(s.res);
+  SPP_GLOBAL uint32_t* evals = G(s.evals);
   const int64_t base = (int64_t)bx_ * kFlagSpan;
-  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  // ---- round trip 1: state words and this workgroup's slice of inv (index clamped: E is not known yet)
+  const int32_t err0 = st->error;
+  const int32_t E = st->E[h];
+  const uint32_t T = (uint32_t)st->cnt[h];
   uint32_t slot[kFlagRounds];
 #pragma unroll
   for (int r = 0; r < kFlagRounds; ++r) {
     const int64_t p = base + r * kFlagNT + threadIdx.x;
-    slot[r] = p < E ? s.inv[p] : 0u;
+    slot[r] = inv[p < pcap ? p : pcap - 1];
   }
+  if (err0) {
+    if (bx_ == 0 && threadIdx.x == 0) {  // keep the later hops' sizes defined
+      st->cnt[h + 1] = (int32_t)T;
+      st->dbase[h + 1] = st->dbase[h];
+    }
+    return;
+  }
+  const int32_t nwg = E > 0 ? (E + kFlagSpan - 1) / kFlagSpan : 1;  // workgroup 0 always takes part
+  if ((int32_t)bx_ >= nwg) return;
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  // ---- round trip 2: the table values, through inv (positions past E read entry 0: no predicate on the load)
   uint32_t val[kFlagRounds];
 #pragma unroll
   for (int r = 0; r < kFlagRounds; ++r) {
     const int64_t p = base + r * kFlagNT + threadIdx.x;
-    val[r] = p < E ? s.res[slot[r]] : 0u;
+    val[r] = res[p < E ? slot[r] : 0u];
   }
   unsigned long long bits[kFlagRounds];
 #pragma unroll
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
     const int64_t p = base + r * kFlagNT + threadIdx.x;
     bool flag = false;
     if (p < E) {
-      s.evals[p] = val[r];
+      evals[p] = val[r];
       flag = (val[r] == T + (uint32_t)p);  // first occurrence of a node that is new in this hop
     }
     bits[r] = __ballot(flag);
@@ -1136,7 +1142,7 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
     const int32_t U = st->cnt[h] + nnew;
     st->cnt[h + 1] = U;
     st->dbase[h + 1] = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
-    if (U > ucap) atomicOr(&st->error, kErrNodeCap);
+    if (U > ucap) atomicOr(&s.st->error, kErrNodeCap);
   }
 }
 
@@ -1148,34 +1154,47 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, ui
 // fast path: one lane per target row.  Local ids of the row's edges (rank lookups for the nodes that
 // are new in this hop), n_ids.push_back for the row's first occurrences (sample_cpu.hpp:50-60), rank
 // sort of the <= 32 ids staged in LDS (sample_cpu.hpp:126).
-__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
+                                                   int32_t tcap) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
   int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(rows_lds);
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t T = s.st->cnt[h];
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* out_rp = G(s.out_rowptr[h]);
+  const SPP_GLOBAL uint32_t* evals = G(s.evals);
+  const SPP_GLOBAL int32_t* cval = G(s.cval);
+  const SPP_GLOBAL RankWord* fwords = G(s.fwords);
+  const SPP_GLOBAL int32_t* fsum = G(s.fsum);
+  SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
   const int32_t i = bx_ * kNT + threadIdx.x;
-  if (i >= T || s.st->error) return;
+  // ---- round trip 1: state words and the row's bounds (index clamped: T is not known yet)
+  const int32_t ic = i < tcap ? i : tcap - 1;
+  const int32_t T = st->cnt[h];
+  const int32_t err0 = st->error;
+  const int32_t p0 = out_rp[ic];
+  const int32_t p1 = out_rp[ic + 1];
+  if (i >= T || err0) return;
   const int tid = threadIdx.x;
-  const int32_t p0 = s.out_rowptr[h][i];
-  const int32_t n = s.out_rowptr[h][i + 1] - p0;
-  // 8 edges at a time; each round's loads are all issued before any of them is used
+  const int32_t n = p1 - p0;
+  // 8 edges at a time; each round's loads are all issued before any of them is used (clamped indices, no
+  // predicated loads: a predicate makes the compiler wait for one load before it issues the next)
   for (int32_t k0 = 0; k0 < n; k0 += 8) {
     uint32_t v[8], q[8];
     int32_t c[8], fs[8];
     RankWord rw[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool on = k0 + u < n;
-      v[u] = on ? s.evals[p0 + k0 + u] : 0u;
-      c[u] = on ? s.cval[p0 + k0 + u] : 0;
+    for (int u = 0; u < 8; ++u) {  // ---- round trip 2
+      const int32_t k = k0 + u < n ? k0 + u : n - 1;
+      v[u] = evals[p0 + k];
+      c[u] = cval[p0 + k];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 8; ++u) {  // ---- round trip 3: rank records of the nodes that are new in this hop (others: record 0)
       const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
       q[u] = fresh ? v[u] - (uint32_t)T : 0u;
-      fs[u] = fresh ? s.fsum[q[u] >> 8] : 0;
-      rw[u] = fresh ? s.fwords[q[u] >> 6] : RankWord{0ull, 0u, 0u};
+      fs[u] = fsum[q[u] >> 8];
+      rw[u] = load_rank_word(fwords, q[u] >> 6);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1183,12 +1202,12 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
       int32_t id = (int32_t)v[u];
       if (v[u] >= (uint32_t)T) {
         id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
-        if (q[u] == (uint32_t)(p0 + k0 + u)) s.n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
+        if (q[u] == (uint32_t)(p0 + k0 + u)) n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
       }
       a[k0 + u][tid] = id;
     }
   }
-  int32_t* out = s.out_col[h] + p0;
+  SPP_GLOBAL int32_t* out = G(s.out_col[h]) + p0;
   for (int32_t k = 0; k < n; ++k) {
     const int32_t v = a[k][tid];
     int32_t rank = 0;
@@ -2147,10 +2166,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     else
       hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
+    // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
+    const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
     hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
-                       (int32_t)s->tcap[H]);
+                       (int32_t)s->tcap[H], pcap);
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
+      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, (int32_t)s->tcap[h]);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];
