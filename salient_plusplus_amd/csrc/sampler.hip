@@ -765,25 +765,35 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                      int32_t cb_log2) {
+                                                      int32_t cb_log2, int64_t pcap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lh[kMaxBuckets];
   __shared__ int32_t lscan[kTileNT / kWave + 1];
   __shared__ int is_last;
   const SlotPtrs& s = slots[gg.first_slot + by_];
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* cval = G(s.cval);
   const int32_t nbk = 1 << cb_log2;  // buckets of THIS hop (coarser than the known lists for small hops)
-  const int32_t E = s.st->error ? 0 : s.st->E[h];
   const int64_t base = (int64_t)bx_ * kBucketTile;
-  if (base >= E && bx_ != 0) return;  // tile 0 always takes part (E may be 0)
-  const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
-  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
-  // the tile's node ids: every load issued before the first use (kTileEPT independent misses per lane)
+  // one round trip: the state words and the tile's node ids (index clamped: E is not known yet; every
+  // load issued before the first use -- kTileEPT independent misses per lane)
+  const int32_t err0 = st->error;
+  const int32_t E0 = st->E[h];
   int32_t v[kTileEPT];
 #pragma unroll
   for (int u = 0; u < kTileEPT; ++u) {
     const int64_t p = base + u * kTileNT + threadIdx.x;
-    v[u] = p < E ? s.cval[p] : -1;  // node ids are >= 0
+    v[u] = cval[p < pcap ? p : pcap - 1];
   }
+  const int32_t E = err0 ? 0 : E0;
+  if (base >= E && bx_ != 0) return;  // tile 0 always takes part (E may be 0)
+  const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
+#pragma unroll
+  for (int u = 0; u < kTileEPT; ++u) {
+    const int64_t p = base + u * kTileNT + threadIdx.x;
+    if (p >= E) v[u] = -1;  // node ids are >= 0
+  }
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kTileEPT; ++u)
@@ -822,7 +832,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
 // inv[p] (where edge p went) is stored in position order -- also coalesced -- so that the per-edge
 // results of k_bucket_dedup can stay in bucket order and be fetched back by reads (k_hop_flag).
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                         int32_t h, int32_t cb_log2) {
+                                                         int32_t h, int32_t cb_log2, int64_t pcap) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t sc_lds[];
   const int32_t nbk = 1 << cb_log2;
@@ -832,16 +842,28 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
   uint16_t* sidx = reinterpret_cast<uint16_t*>(sc_lds + 2 * nbk + kScatterTile);  // [kScatterTile] tile-local edge index
   __shared__ int32_t lscan[kTileNT / kWave + 1];
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t E = s.st->E[h];
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* cval = G(s.cval);
+  SPP_GLOBAL int32_t* bcur = G(s.bcur);
+  SPP_GLOBAL uint32_t* inv = G(s.inv);
+  SPP_GLOBAL unsigned long long* bpairs = G(s.bpairs);
   const int64_t base = (int64_t)bx_ * kScatterTile;
-  if (base >= E || s.st->error) return;
-  for (int b = threadIdx.x; b < nbk; b += kTileNT) cur[b] = 0;
-  int32_t v[kScatterEPT];  // loaded once, every load in flight before the first use
+  // one round trip: the state words and the tile's node ids (index clamped: E is not known yet)
+  const int32_t E = st->E[h];
+  const int32_t err0 = st->error;
+  int32_t v[kScatterEPT];
 #pragma unroll
   for (int u = 0; u < kScatterEPT; ++u) {
     const int64_t p = base + u * kTileNT + threadIdx.x;
-    v[u] = p < E ? s.cval[p] : -1;
+    v[u] = cval[p < pcap ? p : pcap - 1];
   }
+  if (base >= E || err0) return;
+#pragma unroll
+  for (int u = 0; u < kScatterEPT; ++u) {
+    const int64_t p = base + u * kTileNT + threadIdx.x;
+    if (p >= E) v[u] = -1;
+  }
+  for (int b = threadIdx.x; b < nbk; b += kTileNT) cur[b] = 0;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kScatterEPT; ++u)
@@ -862,8 +884,8 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     int32_t off = block_exclusive_scan<int32_t, kTileNT>(sum, lscan, &tot);
 #pragma unroll
     for (int k = 0; k < kMaxBuckets / kTileNT; ++k) {
-      if (k < per && b0 + k < nbk) {
-        const int32_t g = c[k] ? atomicAdd(&s.bcur[b0 + k], c[k]) : 0;
+      if (k < per && b0 + k < nbk) {  // (usually per == 1: one reservation per thread)
+        const int32_t g = c[k] ? __hip_atomic_fetch_add(bcur + b0 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         cur[b0 + k] = off;
         delta[b0 + k] = g - off;
         off += c[k];
@@ -880,14 +902,14 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     const int32_t li = u * kTileNT + threadIdx.x;
     snode[slot] = c;
     sidx[slot] = (uint16_t)li;
-    s.inv[base + li] = (uint32_t)(slot + delta[b]);
+    inv[base + li] = (uint32_t)(slot + delta[b]);
   }
   __syncthreads();
   const int32_t n_tile = (int32_t)((E - base) < kScatterTile ? (E - base) : kScatterTile);
   for (int k = threadIdx.x; k < n_tile; k += kTileNT) {
     const uint32_t c = snode[k];
     const int32_t dst = k + delta[bucket_of(c, cb_log2)];
-    s.bpairs[dst] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
+    bpairs[dst] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
   }
 }
 
@@ -1154,47 +1176,34 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, ui
 // fast path: one lane per target row.  Local ids of the row's edges (rank lookups for the nodes that
 // are new in this hop), n_ids.push_back for the row's first occurrences (sample_cpu.hpp:50-60), rank
 // sort of the <= 32 ids staged in LDS (sample_cpu.hpp:126).
-__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                   int32_t tcap) {
+__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
   int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(rows_lds);
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const SPP_GLOBAL SlotState* st = G(s.st);
-  const SPP_GLOBAL int32_t* out_rp = G(s.out_rowptr[h]);
-  const SPP_GLOBAL uint32_t* evals = G(s.evals);
-  const SPP_GLOBAL int32_t* cval = G(s.cval);
-  const SPP_GLOBAL RankWord* fwords = G(s.fwords);
-  const SPP_GLOBAL int32_t* fsum = G(s.fsum);
-  SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
+  const int32_t T = s.st->cnt[h];
   const int32_t i = bx_ * kNT + threadIdx.x;
-  // ---- round trip 1: state words and the row's bounds (index clamped: T is not known yet)
-  const int32_t ic = i < tcap ? i : tcap - 1;
-  const int32_t T = st->cnt[h];
-  const int32_t err0 = st->error;
-  const int32_t p0 = out_rp[ic];
-  const int32_t p1 = out_rp[ic + 1];
-  if (i >= T || err0) return;
+  if (i >= T || s.st->error) return;
   const int tid = threadIdx.x;
-  const int32_t n = p1 - p0;
-  // 8 edges at a time; each round's loads are all issued before any of them is used (clamped indices, no
-  // predicated loads: a predicate makes the compiler wait for one load before it issues the next)
+  const int32_t p0 = s.out_rowptr[h][i];
+  const int32_t n = s.out_rowptr[h][i + 1] - p0;
+  // 8 edges at a time; each round's loads are all issued before any of them is used
   for (int32_t k0 = 0; k0 < n; k0 += 8) {
     uint32_t v[8], q[8];
     int32_t c[8], fs[8];
     RankWord rw[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // ---- round trip 2
-      const int32_t k = k0 + u < n ? k0 + u : n - 1;
-      v[u] = evals[p0 + k];
-      c[u] = cval[p0 + k];
+    for (int u = 0; u < 8; ++u) {
+      const bool on = k0 + u < n;
+      v[u] = on ? s.evals[p0 + k0 + u] : 0u;
+      c[u] = on ? s.cval[p0 + k0 + u] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // ---- round trip 3: rank records of the nodes that are new in this hop (others: record 0)
+    for (int u = 0; u < 8; ++u) {
       const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
       q[u] = fresh ? v[u] - (uint32_t)T : 0u;
-      fs[u] = fsum[q[u] >> 8];
-      rw[u] = load_rank_word(fwords, q[u] >> 6);
+      fs[u] = fresh ? s.fsum[q[u] >> 8] : 0;
+      rw[u] = fresh ? s.fwords[q[u] >> 6] : RankWord{0ull, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1202,12 +1211,12 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
       int32_t id = (int32_t)v[u];
       if (v[u] >= (uint32_t)T) {
         id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
-        if (q[u] == (uint32_t)(p0 + k0 + u)) n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
+        if (q[u] == (uint32_t)(p0 + k0 + u)) s.n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
       }
       a[k0 + u][tid] = id;
     }
   }
-  SPP_GLOBAL int32_t* out = G(s.out_col[h]) + p0;
+  int32_t* out = s.out_col[h] + p0;
   for (int32_t k = 0; k < n; ++k) {
     const int32_t v = a[k][tid];
     int32_t rank = 0;
@@ -2153,10 +2162,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
     const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
-    hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb);
+    // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
+    const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
+    hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap);
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap);
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 12)
@@ -2166,12 +2177,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     else
       hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
-    // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
-    const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
     hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
                        (int32_t)s->tcap[H], pcap);
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, (int32_t)s->tcap[h]);
+      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];
