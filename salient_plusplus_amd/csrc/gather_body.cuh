@@ -61,10 +61,13 @@ static inline GatherGeom gather_geometry(const void* src, const void* dst, int64
 // 490 MB table, sustained): plain loads 63 us, non-temporal loads 88-93 us -- the rows are not
 // really read-once (hub rows repeat across batches and MALL/L2 catch them), so plain is the default;
 // the stores stay non-temporal.
-// move_rows_body: dst[r,:] = *src_of(r) for r < n; `src_of` maps an output row to its source row.
-template <int VEC, bool kNT, typename SrcFn>
-__device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
-                                               char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+// move_rows_body: dst[r,:] = *ptr_of(key_of(r)) for r < n.  The source of an output row comes in two steps so
+// that the loads of a round really are in flight together: key_of(r) is a pure load (an index, a source
+// record), ptr_of(key) turns it into the row's address (range checks, selects).  A single functor doing
+// both put control flow between the loads and the compiler waited for each before issuing the next.
+template <int VEC, bool kNT, typename KeyFn, typename PtrFn>
+__device__ __forceinline__ void move_rows_body(KeyFn key_of, PtrFn ptr_of, int64_t n, int64_t row_bytes, int chunks,
+                                               int lpr_log2, char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
   using V = typename vec_of<VEC>::type;
   const int lpr = 1 << lpr_log2;
   const int g = threadIdx.x >> lpr_log2;
@@ -75,7 +78,8 @@ __device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t 
     // Branch-free loads: a row index past the end is clamped to the last row (loaded, never stored).  With
     // `if (ok) v = load` the compiler put every load in its own exec-masked block behind an
     // s_waitcnt vmcnt(0) -- ONE load in flight per wavefront whatever the unroll; now the kGatherUnroll
-    // index loads, then the kGatherUnroll row loads, are issued back to back.
+    // key loads, then the kGatherUnroll row loads, are issued back to back.
+    decltype(key_of((int64_t)0)) key[kGatherUnroll];
     const V* s[kGatherUnroll];
     V* d[kGatherUnroll];
     bool ok[kGatherUnroll];
@@ -83,9 +87,11 @@ __device__ __forceinline__ void move_rows_body(SrcFn src_of, int64_t n, int64_t 
     for (int u = 0; u < kGatherUnroll; ++u) {
       const int64_t r = base + (int64_t)u * gpb + g;
       ok[u] = r < n;
-      s[u] = reinterpret_cast<const V*>(src_of(ok[u] ? r : n - 1));
+      key[u] = key_of(ok[u] ? r : n - 1);
       d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
     }
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) s[u] = reinterpret_cast<const V*>(ptr_of(key[u]));
     for (int c = l; c < chunks; c += lpr) {
       V v[kGatherUnroll];
 #pragma unroll
@@ -103,8 +109,8 @@ __device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, c
                                                  char* __restrict__ dst, int64_t vblock, int64_t nvblocks,
                                                  int64_t src_stride) {
   if (n <= 0) return;
-  move_rows_body<VEC, kNT>([=](int64_t r) { return src + (int64_t)idx[r] * src_stride; }, n, row_bytes, chunks,
-                           lpr_log2, dst, vblock, nvblocks);
+  move_rows_body<VEC, kNT>([=](int64_t r) { return idx[r]; }, [=](IdxT i) { return src + (int64_t)i * src_stride; }, n,
+                           row_bytes, chunks, lpr_log2, dst, vblock, nvblocks);
 }
 
 // Same with caller-supplied (untrusted) indices: an index outside [0, src_rows) reads row 0 and raises
@@ -117,8 +123,9 @@ __device__ __forceinline__ void gather_rows_checked_body(const char* __restrict_
                                                          int32_t* err, int32_t err_bit) {
   if (n <= 0) return;
   move_rows_body<VEC, kNT>(
-      [=](int64_t r) {
-        int64_t i = (int64_t)idx[r];
+      [=](int64_t r) { return idx[r]; },
+      [=](IdxT k) {
+        int64_t i = (int64_t)k;
         if ((uint64_t)i >= (uint64_t)src_rows) {
           if (err) __hip_atomic_fetch_or(err, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           i = 0;

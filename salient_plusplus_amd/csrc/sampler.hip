@@ -1469,8 +1469,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
     } else {
       // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes
       move_rows_body<VEC, false>(
-          [&](int64_t r) -> const char* {
-            const int2 c = a.psrc[r];  // {bucket, row} written by k_gpart_scatter: one load before the row's own
+          [&](int64_t r) { return a.psrc[r]; },  // {bucket, row} written by k_gpart_scatter: one load before the row's own
+          [&](int2 c) -> const char* {
             if (c.x == a.rank) return a.x_src + (int64_t)c.y * a.x_src_stride;
             if (c.x == a.P) return a.cache + (int64_t)c.y * a.cache_stride;
             return a.recv + (a.recv_base[c.x] + c.y) * a.x_row_bytes;

@@ -54,8 +54,9 @@ __global__ __launch_bounds__(kGatherThreads) void k_serve_rows(const char* __res
                                                                int64_t src_stride, int chunks, int lpr_log2,
                                                                char* __restrict__ out, int32_t* err) {
   move_rows_body<VEC, false>(
-      [=](int64_t j) -> const char* {
-        int64_t r = (int64_t)ids[j] - rank_offset;
+      [=](int64_t j) { return ids[j]; },
+      [=](int32_t id) -> const char* {
+        int64_t r = (int64_t)id - rank_offset;
         if ((uint64_t)r >= (uint64_t)x_rows) {
           // a peer only asks for rows this rank owns: anything else is a bucketing / partition-book
           // mismatch between the ranks -- serve row 0 (no fault) and report it (SPP_AERR_SERVE_ID)
