@@ -429,43 +429,71 @@ __device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expect
 
 // One WAVEFRONT per 256 targets (the unit k_hop_pick's workgroups work in): four targets per lane, their
 // loads in flight together, and the unit's two sums by a wavefront reduction -- no LDS, no barrier.
+// Two round trips: {state words, node ids, stored degrees} at clamped indices, then the row headers --
+// unpredicated (lanes without a new target read node 0's header): a predicate on a load makes the
+// compiler wait for it before it issues the next one.
 __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                     const int64_t* __restrict__ rowptr,
                                                     const stub4* __restrict__ stubs, int32_t h, int32_t f,
-                                                    int32_t replace) {
+                                                    int32_t replace, int32_t tcap) {
   SPP_GROUP_BLOCK(gg);
   constexpr int kPer = kNT / kWave;  // targets per lane
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t T = s.st->cnt[h];
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
+  SPP_GLOBAL int32_t* degp = G(s.deg);
+  SPP_GLOBAL int64_t* rsp = G(s.rowstart);
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t unit = (int64_t)bx_ * (kNT / kWave) + threadIdx.x / kWave;  // index of the 256-target unit
   const int64_t i0 = unit * kNT;
-  if (i0 >= T) return;
-  const int32_t Tprev = h > 0 ? s.st->cnt[h - 1] : 0;
+  if (i0 >= tcap) return;
+  const int32_t T = st->cnt[h];
+  const int32_t Tprev = h > 0 ? st->cnt[h - 1] : 0;
   int32_t v[kPer], deg[kPer];
-  int64_t rs[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int64_t i = i0 + u * kWave + lane;
-    // a target of the previous hop as well: its degree and row start are still in place
-    v[u] = (i < T && i >= Tprev) ? s.n_ids[i] : -1;
-    deg[u] = (i < T && i < Tprev) ? s.deg[i] : 0;
+    const int64_t ic = i < tcap ? i : tcap - 1;
+    v[u] = n_ids[ic];
+    deg[u] = degp[ic];  // a target of the previous hop as well: its degree and row start are still in place
   }
+  if (i0 >= T) return;
+  int64_t rs[kPer];
   int32_t nd[kPer];
+  bool fresh[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
-    nd[u] = 0;
-    rs[u] = 0;
-    if (v[u] >= 0) row_header(rowptr, stubs, v[u], nd[u], rs[u]);
+    const int64_t i = i0 + u * kWave + lane;
+    fresh[u] = i < T && i >= Tprev;
+    if (!fresh[u]) v[u] = 0;
+  }
+  if (stubs) {
+    stub4 hd[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) hd[u] = stubs[(int64_t)v[u] * 8];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      nd[u] = hd[u].x;
+      rs[u] = ((int64_t)hd[u].z << 32) | (uint32_t)hd[u].y;
+    }
+  } else {
+    int64_t re[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      rs[u] = rowptr[v[u]];
+      re[u] = rowptr[v[u] + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) nd[u] = (int32_t)(re[u] - rs[u]);
   }
   int32_t cnt = 0, smp = 0;
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
     const int64_t i = i0 + u * kWave + lane;
-    if (v[u] >= 0) {
+    if (fresh[u]) {
       deg[u] = nd[u];
-      s.deg[i] = deg[u];
-      s.rowstart[i] = rs[u];
+      degp[i] = nd[u];
+      rsp[i] = rs[u];
     }
     if (i < T) {
       int32_t c, m;
@@ -477,8 +505,8 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
   cnt = wave_inclusive_scan(cnt);
   smp = wave_inclusive_scan(smp);
   if (lane == kWave - 1) {
-    s.bsum0[unit] = cnt;
-    s.bsum1[unit] = smp;
+    G(s.bsum0)[unit] = cnt;
+    G(s.bsum1)[unit] = smp;
   }
 }
 
@@ -2115,7 +2143,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
     if (h > 0) {
       const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
-      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, h, f, replace);
+      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, h, f, replace, (int32_t)s->tcap[h]);
     }
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
