@@ -1283,35 +1283,82 @@ struct PartDev {
   const int32_t* cache_map;
   int64_t cache_len;
   int32_t nblk_cap;  // row pitch of pblk
+  // membership bits of the cache map (bit v set: cache_map[v] >= 0), rebuilt from the map at every Session
+  // start: N/8 bytes stay cache resident (14 MB for 111 M nodes), where a 4-byte lookup per remote node
+  // in the 444 MB map was one HBM line each -- more lines per batch than the neighbour reads
+  const uint32_t* cache_bits;
 };
+
+__global__ __launch_bounds__(256) void k_cache_bits(const int32_t* __restrict__ map, int64_t len,
+                                                    unsigned long long* __restrict__ bits64) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t nwords = (len + 63) / 64;
+  for (int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kWave; w < nwords; w += (int64_t)gridDim.x * (256 / kWave)) {
+    const int64_t i = w * 64 + lane;
+    const int32_t m = map[i < len ? i : len - 1];
+    const unsigned long long mask = __ballot(i < len && m >= 0);
+    if (lane == 0) bits64[w] = mask;
+  }
+}
 
 constexpr int kPartRounds = 4;                   // nodes per thread of k_gpart_hist / k_gpart_scatter
 constexpr int kPartSpan = kNT * kPartRounds;     // nodes per workgroup (one row entry of pblk)
 
+// bucket of node v when the cache map entry `m` of v is already in hand (part_bucket_of, partition_common.cuh)
+__device__ __forceinline__ int32_t part_bucket_with(const Offsets& off, int32_t P, int32_t rank, int32_t use_cache,
+                                                    int32_t m, int64_t v) {
+  if (!use_cache) return owner_of(off, v);
+  if (v >= off.v[rank] && v < off.v[rank + 1]) return rank;
+  if (m >= 0) return P;
+  return owner_of(off, v);
+}
+
 __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t H,
-                                                    PartDev a) {
+                                                    PartDev a, int32_t ucap) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t cnt[kPartBuckets];
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)bx_ * kPartSpan >= U) return;
-  for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
+  SPP_GLOBAL uint8_t* pbucket = G(s.pbucket);
+  // round trip 1: state words and the node ids (clamped index: U is not known yet)
+  const int32_t err0 = st->error;
+  const int32_t U0 = st->cnt[H];
   int32_t v[kPartRounds];
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
-    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
-    v[r] = i < U ? s.n_ids[i] : -1;  // node ids are >= 0
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
+    v[r] = n_ids[i < ucap ? i : ucap - 1];
+  }
+  const int32_t U = err0 ? 0 : U0;
+  if ((int64_t)bx_ * kPartSpan >= U) return;
+  for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
+  // round trip 2: the cache map entries of the remote nodes (others read entry 0: no predicate on the load)
+  int32_t cm[kPartRounds];
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
+    if (i >= U) v[r] = -1;  // node ids are >= 0
+    const int64_t vv = v[r];
+    const bool look = a.use_cache && vv >= 0 && vv < a.cache_len && !(vv >= a.off.v[a.rank] && vv < a.off.v[a.rank + 1]);
+    if (a.cache_bits) {
+      const uint32_t w = a.cache_bits[look ? (vv >> 5) : 0];
+      cm[r] = (look && ((w >> (vv & 31)) & 1u)) ? 0 : -1;  // only the sign is used: >= 0 = cached
+    } else {  // no Session built the bits (stand-alone spp_sampler_sample): the map itself
+      cm[r] = a.use_cache ? a.cache_map[look ? vv : 0] : -1;
+      if (!look) cm[r] = -1;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
-    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
     const bool valid = v[r] >= 0;
     int32_t b = -1;
     if (valid) {
-      b = part_bucket_of(a.off, a.P, a.rank, a.use_cache, a.cache_map, a.cache_len, (int64_t)v[r]);
-      s.pbucket[i] = (uint8_t)b;
+      b = part_bucket_with(a.off, a.P, a.rank, a.use_cache, cm[r], (int64_t)v[r]);
+      pbucket[i] = (uint8_t)b;
     }
     // one LDS atomic per (wavefront, bucket present in it) instead of one per node: most nodes of a
     // wavefront share an owner, and 64 lanes hammering one counter serialise
@@ -1325,7 +1372,7 @@ __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k <= a.P; k += kNT) s.pblk[(int64_t)k * a.nblk_cap + bx_] = cnt[k];
+  for (int k = threadIdx.x; k <= a.P; k += kNT) G(s.pblk)[(int64_t)k * a.nblk_cap + bx_] = cnt[k];
 }
 
 // one wavefront per bucket: exclusive scan of the bucket's per-workgroup counts
@@ -1353,31 +1400,48 @@ __global__ __launch_bounds__(kScanNT) void k_gpart_scan(const SlotPtrs* __restri
 }
 
 __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                       int32_t H, PartDev a) {
+                                                       int32_t H, PartDev a, int32_t ucap) {
   SPP_GROUP_BLOCK(gg);
   constexpr int kW = kNT / kWave;
   __shared__ int32_t wcnt[kPartRounds * kW][kPartBuckets];  // [round][wavefront]: the order nodes appear in
   __shared__ int32_t base[kPartBuckets];
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const int32_t U = s.st->error ? 0 : s.st->cnt[H];
-  if ((int64_t)bx_ * kPartSpan >= U) return;
-  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  for (int k = threadIdx.x; k < kPartRounds * kW * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
-  if (threadIdx.x == 0) {
-    int32_t acc = 0;
-    for (int m = 0; m <= a.P; ++m) {  // concat order: parts[0..P-1] then cache hits
-      base[m] = acc;
-      acc += s.st->pcnt[m];
-    }
-  }
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
+  const SPP_GLOBAL uint8_t* pbucket = G(s.pbucket);
+  const SPP_GLOBAL int32_t* pblk = G(s.pblk);
+  // round trip 1: state words, bucket sizes (one lane each), this workgroup's nodes and their buckets
+  // (clamped index: U is not known yet)
+  const int32_t err0 = st->error;
+  const int32_t U0 = st->cnt[H];
+  const int32_t my_pcnt = (int)threadIdx.x <= a.P ? st->pcnt[threadIdx.x] : 0;
   int32_t b[kPartRounds], v[kPartRounds], rank_w[kPartRounds];
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
-    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
-    b[r] = i < U ? (int32_t)s.pbucket[i] : -1;
-    v[r] = i < U ? s.n_ids[i] : 0;
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
+    const int64_t ic = i < ucap ? i : ucap - 1;
+    b[r] = (int32_t)pbucket[ic];
+    v[r] = n_ids[ic];
+  }
+  const int32_t U = err0 ? 0 : U0;
+  if ((int64_t)bx_ * kPartSpan >= U) return;
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  for (int k = threadIdx.x; k < kPartRounds * kW * kPartBuckets; k += kNT) (&wcnt[0][0])[k] = 0;
+  if ((int)threadIdx.x <= a.P) base[threadIdx.x] = my_pcnt;  // sizes now, offsets after the barrier
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
+    if (i >= U) b[r] = -1;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {  // concat order: parts[0..P-1] then cache hits (sizes -> exclusive offsets, in LDS)
+    int32_t acc = 0;
+    for (int m = 0; m <= a.P; ++m) {
+      const int32_t c = base[m];
+      base[m] = acc;
+      acc += c;
+    }
+  }
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
@@ -1397,21 +1461,29 @@ __global__ __launch_bounds__(kNT) void k_gpart_scatter(const SlotPtrs* __restric
     }
   }
   __syncthreads();
+  // round trip 2: this workgroup's offsets inside the buckets and the cache rows of the cache hits
+  int32_t boff[kPartRounds], crow[kPartRounds];
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    const int32_t bb = b[r] >= 0 ? b[r] : 0;
+    boff[r] = pblk[(int64_t)bb * a.nblk_cap + bx_];
+    crow[r] = a.use_cache ? a.cache_map[b[r] == a.P ? v[r] : 0] : 0;
+  }
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
     if (b[r] < 0) continue;
-    const int32_t i = bx_ * kPartSpan + r * kNT + threadIdx.x;
+    const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
     int32_t pre = 0;
     for (int w = 0; w < r * kW + wid; ++w) pre += wcnt[w][b[r]];
-    const int32_t pos = base[b[r]] + s.pblk[(int64_t)b[r] * a.nblk_cap + bx_] + pre + rank_w[r];
-    s.pperm[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
-    int32_t src_row;   // for the fused assembly (k_deliver): one record per node instead of pperm -> segment search -> id
+    const int32_t pos = base[b[r]] + boff[r] + pre + rank_w[r];
+    G(s.pperm)[i] = pos;  // perm_partition_to_mfg (:1085 / :1246-1252)
+    int32_t src_row;      // for the fused assembly (k_deliver): one record per node instead of pperm -> segment search -> id
     if (b[r] < a.P) {
-      s.parts[pos] = v[r];
+      G(s.parts)[pos] = v[r];
       src_row = (b[r] == a.rank) ? (int32_t)((int64_t)v[r] - a.off.v[a.rank]) : pos - base[b[r]];
     } else {
-      src_row = a.cache_map[v[r]];  // nid2cachenid (:1256)
-      s.pcached[pos - base[a.P]] = src_row;
+      src_row = crow[r];  // nid2cachenid (:1256)
+      G(s.pcached)[pos - base[a.P]] = src_row;
     }
     s.psrc[i] = int2{b[r], src_row};
   }
@@ -1607,6 +1679,8 @@ struct spp_sampler {
   int64_t rng_arena_seeds_cap = 0;
   hipEvent_t rng_arena_ready = nullptr;
   hipEvent_t inputs_ready = nullptr;  // sampler_inputs_event
+  unsigned long long* cache_bits = nullptr;  // PartDev::cache_bits (owned)
+  hipEvent_t cache_bits_ready = nullptr;
   std::unique_ptr<Worker> workers[2];  // persistent host threads lent to Sessions (sampler_worker)
   bool xcd_affinity = true;          // GroupGrid.interleave of the grouped launches (SPP_XCD_AFFINITY=0: batch-major ids)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
@@ -1935,6 +2009,8 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   if (s->rng_arena_seeds_dev) (void)hipFree(s->rng_arena_seeds_dev);
   if (s->rng_arena_ready) (void)hipEventDestroy(s->rng_arena_ready);
   if (s->inputs_ready) (void)hipEventDestroy(s->inputs_ready);
+  if (s->cache_bits_ready) (void)hipEventDestroy(s->cache_bits_ready);
+  if (s->cache_bits) (void)hipFree(s->cache_bits);
   if (s->h_states) (void)hipHostFree(s->h_states);
   if (s->deliver_stream) (void)hipStreamDestroy(s->deliver_stream);
   for (auto st : s->work_streams)
@@ -2234,9 +2310,9 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   }
   if (s->part.P > 0) {
     const unsigned gu = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[H], kPartSpan));
-    hipLaunchKernelGGL(k_gpart_hist, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
+    hipLaunchKernelGGL(k_gpart_hist, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part, (int32_t)s->tcap[H]);
     hipLaunchKernelGGL(k_gpart_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), H, s->part);
-    hipLaunchKernelGGL(k_gpart_scatter, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part);
+    hipLaunchKernelGGL(k_gpart_scatter, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part, (int32_t)s->tcap[H]);
   }
   SPP_HIP_TRY(hipGetLastError());
   SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -2416,6 +2492,28 @@ hipStream_t sampler_comm_stream(spp_sampler* s) {
 void sampler_poison_comm_stream(spp_sampler* s) { s->comm_stream = nullptr; }  // leaked on purpose
 
 hipEvent_t sampler_export_event(spp_sampler* s, int slot) { return s->slots[(size_t)slot].exported; }
+
+// Rebuilds the cache membership bits from the map on `st` (a Session calls this once, before its first
+// chain: the map may have been rebuilt in place since the last Session) and returns the event that marks
+// them ready; *ready == NULL: this sampler has no cache.
+spp_status sampler_refresh_cache_bits(spp_sampler* s, hipStream_t st, hipEvent_t* ready) {
+  *ready = nullptr;
+  if (s->part.P <= 0 || !s->part.use_cache || !s->part.cache_map || s->part.cache_len <= 0) return SPP_OK;
+  const int64_t nwords = (s->part.cache_len + 63) / 64;
+  if (!s->cache_bits) {
+    SPP_HIP_TRY(hipSetDevice(s->cfg.device));
+    SPP_HIP_TRY(hipMalloc((void**)&s->cache_bits, sizeof(unsigned long long) * (size_t)nwords));
+    s->bytes += (int64_t)sizeof(unsigned long long) * nwords;
+    s->part.cache_bits = reinterpret_cast<const uint32_t*>(s->cache_bits);
+  }
+  if (!s->cache_bits_ready) SPP_HIP_TRY(hipEventCreateWithFlags(&s->cache_bits_ready, hipEventDisableTiming));
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(nwords, 256 / kWave), 256 * 16);
+  hipLaunchKernelGGL(k_cache_bits, dim3(grid), dim3(256), 0, st, s->part.cache_map, s->part.cache_len, s->cache_bits);
+  SPP_HIP_TRY(hipGetLastError());
+  SPP_HIP_TRY(hipEventRecord(s->cache_bits_ready, st));
+  *ready = s->cache_bits_ready;
+  return SPP_OK;
+}
 
 hipEvent_t sampler_inputs_event(spp_sampler* s) {
   if (!s->inputs_ready && hipEventCreateWithFlags(&s->inputs_ready, hipEventDisableTiming) != hipSuccess)

@@ -156,6 +156,10 @@ spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t n
 // saw its teardown take 35-80 ms every few epochs (the runtime recycling its signal pool).
 hipEvent_t sampler_export_event(spp_sampler* s, int slot);
 hipEvent_t sampler_inputs_event(spp_sampler* s);
+
+// cache membership bits of the ownership bucketing, rebuilt from the cache map on `st`; *ready is the event to
+// order the sampling streams after (NULL: no cache)
+spp_status sampler_refresh_cache_bits(spp_sampler* s, hipStream_t st, hipEvent_t* ready);
 // completion event of the group `slot` belongs to (NULL when nothing was sampled into it)
 hipEvent_t sampler_slot_event(const spp_sampler* s, int slot);
 

@@ -627,6 +627,18 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
     after_inputs(as_stream(spp_sampler_deliver_stream(s->sampler)));
     if (s->comm_stream) after_inputs(s->comm_stream);
   }
+  // cache membership bits (ownership bucketing with a cache): rebuilt from the map at every Session start,
+  // on the first sampling stream; the others wait for them
+  if (rc == SPP_OK) {
+    hipEvent_t bits_ready = nullptr;
+    rc = sampler_refresh_cache_bits(s->sampler, s->streams[0], &bits_ready);
+    if (rc == SPP_OK && bits_ready)
+      for (size_t k = 1; k < s->streams.size(); ++k)
+        if (hipStreamWaitEvent(s->streams[k], bits_ready, 0) != hipSuccess) {
+          set_error("spp_session_create: hipStreamWaitEvent failed");
+          rc = SPP_ERR_HIP;
+        }
+  }
   // mt19937 streams of the whole epoch: generated once per range table, kept by the (pooled) sampler
   if (rc == SPP_OK && nb > 0) {
     std::vector<uint32_t> seeds((size_t)nb);

@@ -104,6 +104,19 @@ def chain_only():
             cfg.sizes[i] = f
         cfg.force_exact_num_batches, cfg.exact_num_batches = 1, wl.train_idx.numel() // wl.batch_size
         cfg.max_items_in_queue, cfg.group_size, cfg.device = slots, group, 0
+        part = None
+        if os.environ.get("CHAIN_PARTS"):        # e.g. CHAIN_PARTS=8: ownership bucketing of rank 0 of 8 (+ a 10 % cache map)
+            P_ = int(os.environ["CHAIN_PARTS"])
+            part = nat.PartitionCfg()
+            part.num_parts, part.rank = P_, 0
+            for k in range(P_ + 1):
+                part.offsets[k] = wl.num_nodes * k // P_
+            if os.environ.get("CHAIN_CACHE", "1") != "0":
+                cmap = torch.full((wl.num_nodes,), -1, dtype=torch.int32, device=dev)
+                hit = torch.randperm(wl.num_nodes, device=dev)[: wl.num_nodes // (10 * P_)]
+                cmap[hit] = torch.arange(hit.numel(), dtype=torch.int32, device=dev)
+                part.use_cache, part.cache_map_dev, part.cache_map_len = 1, cmap.data_ptr(), wl.num_nodes
+            cfg.part = C.pointer(part)
         h = C.c_void_p()
         nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
         d = nat.BatchDesc()
