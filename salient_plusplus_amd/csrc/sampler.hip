@@ -1496,18 +1496,30 @@ __global__ __launch_bounds__(kNT) void k_pack_remote_ids(const SlotPtrs* __restr
                                                          const int64_t* __restrict__ pack_base,
                                                          int32_t* __restrict__ out) {
   SPP_GROUP_BLOCK(gg);
+  __shared__ int32_t seg_start[SPP_MAX_PARTS + 1];  // exclusive offsets of the owners' segments in `parts`
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const SlotState* st = s.st;
-  if (st->error) return;
-  const int32_t j = bx_ * kNT + threadIdx.x;
-  int32_t seg = 0, m = 0;
-  for (; m < P; ++m) {
-    const int32_t c = st->pcnt[m];
-    if (j < seg + c) break;
-    seg += c;
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  // the bucket sizes: one lane each, then a serial prefix in LDS (a per-thread loop over st->pcnt[] was up
+  // to P dependent global loads for every thread)
+  const int32_t err0 = st->error;
+  if ((int)threadIdx.x < P) seg_start[threadIdx.x + 1] = st->pcnt[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t acc = 0;
+    seg_start[0] = 0;
+    for (int m = 1; m <= P; ++m) {
+      acc += seg_start[m];
+      seg_start[m] = acc;
+    }
   }
-  if (m >= P || m == rank) return;
-  out[pack_base[(int64_t)by_ * P + m] + (j - seg)] = s.parts[j];
+  __syncthreads();
+  if (err0) return;
+  const int32_t j = bx_ * kNT + threadIdx.x;
+  if (j >= seg_start[P]) return;
+  int32_t m = 0;
+  while (m + 1 < P && j >= seg_start[m + 1]) ++m;
+  if (m == rank) return;
+  out[pack_base[(int64_t)by_ * P + m] + (j - seg_start[m])] = G(s.parts)[j];
 }
 
 // ----------------------------------------------------------------------------------------------
