@@ -988,6 +988,16 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     fkc[i] = kcount[fb0 + i];
     fnew[i] = 0;
   }
+  // (speculative, same round trip as the pairs below: the first 4 x 64 entries of this wavefront's first
+  // fine list -- the list's length is not known yet, entries past it are dropped; kcap >= 256)
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned long long kpre[4];
+  {
+    const int lf0 = threadIdx.x / kWave;
+    const SPP_GLOBAL unsigned long long* kl0 = known + (int64_t)(fb0 + (lf0 < nf ? lf0 : 0)) * g.kcap;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kpre[u] = kl0[lane + u * kWave];
+  }
   if (err0) return;
   const bool work = e1 > e0;  // block-uniform
   // ---- round trip 2.  This hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in
@@ -1007,20 +1017,25 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   // known nodes: resolve the previous hop's pending ids (its first-occurrence bitmap is overwritten by
   // this hop's k_hop_flag, so this must happen now for EVERY list), then publish them in the LDS table;
   // one wavefront per fine list
-  const int lane = threadIdx.x & (kWave - 1);
   for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
     SPP_GLOBAL unsigned long long* kl = known + (int64_t)(fb0 + lf) * g.kcap;
     const int32_t kc = fkc[lf];
+    const bool first_list = lf == (int)(threadIdx.x / kWave);
     for (int i0 = lane; i0 < kc; i0 += 4 * kWave) {  // 4 entries per lane and round, loads batched
       unsigned long long e[4];
       uint32_t q[4];
       RankWord rw[4];
       int32_t fs[4];
+      if (first_list && i0 == lane) {  // fetched with the pairs
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * kWave;
-        const unsigned long long v = kl[i < kc ? i : 0];  // kc > 0 here
-        e[u] = i < kc ? v : kEmptySlot;
+        for (int u = 0; u < 4; ++u) e[u] = (i0 + u * kWave < kc) ? kpre[u] : kEmptySlot;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kWave;
+          const unsigned long long v = kl[i < kc ? i : 0];  // kc > 0 here
+          e[u] = i < kc ? v : kEmptySlot;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {  // rank records of the pending entries (others read record 0: no branch)
