@@ -206,6 +206,59 @@ def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache, size
     assert nb == 3
 
 
+def test_cache_map_rebuilt_in_place_between_sessions(fs, graph_a):
+    """The bucketing kernels test cache membership through a bitmap derived from the cache map; the pooled
+    sampler keeps it across Sessions, so it is rebuilt at every Session start.  Two Sessions over the SAME map
+    buffer, its contents rewritten in between (a cache rebuilt in place): the second must bucket by the new
+    contents."""
+    from oracle import oracle as orc
+    from salient_plusplus_amd import _native as nat
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    import ctypes as C
+    P, rank, sizes = 4, 1, [15, 10, 5]
+    offs = np.array([0, 700, 1500, 2100, 3000], dtype=np.int64)
+    n = graph_a["rowptr"].shape[0] - 1
+    x = graph_a["x"]
+    lo, hi = int(offs[rank]), int(offs[rank + 1])
+    remote = np.setdiff1d(np.arange(n), np.arange(lo, hi))
+    rng = np.random.default_rng(77)
+    cv_a = np.sort(rng.choice(remote, size=300, replace=False)).astype(np.int64)
+    cv_b = np.sort(rng.choice(remote, size=300, replace=False)).astype(np.int64)
+    cv_b[-1] = cv_a.max()                                   # same map length (max id + 1)
+    cv_b = np.unique(cv_b)
+    cache = fs.Cache(rank, P, T(cv_a), T(x[cv_a].copy()))
+    shared_map = cache.device_map()                         # the buffer both Sessions will see
+
+    def run(cv):
+        ocache = orc.Cache(cv, n)
+        cfg = make_cfg(fs, graph_a, sizes, 64, x[lo:hi][100:].copy(), graph_a["y"], graph_a["idx"],
+                       x_gpu=T(x[lo:hi][:100].copy()).cuda(), distributed=True,
+                       partition_book=fs.RangePartitionBook(rank, P, T(offs)), cache=cache,
+                       force_exact_num_batches=True, exact_num_batches=3, use_cache=True)
+        ranges = orc.batch_ranges(200, 64, False, True, 3)
+        for b, proto in enumerate(iter(FastSampler(2, 4, cfg))):
+            start, stop = int(ranges[b][0]), int(ranges[b][1])
+            m = orc.sample_batch(graph_a["rowptr"], graph_a["col"], graph_a["idx"], start, stop, sizes)
+            want = orc.partition_batch(m.n_id, offs, rank, ocache, 0)
+            for k in range(P):
+                np.testing.assert_array_equal(proto.partition_nids[k].cpu().numpy(), want.partition_nids[k])
+            np.testing.assert_array_equal(proto.cached_nids.cpu().numpy(), want.cached_nids)
+            np.testing.assert_array_equal(proto.perm_partition_to_mfg.cpu().numpy(), want.perm_partition_to_mfg)
+
+    run(cv_a)
+    # rewrite the SAME device buffer with cache B's map
+    L = nat.load()
+    cvb_dev = T(cv_b).cuda()
+    nat.check(L.spp_cache_build_map(C.c_void_p(cvb_dev.data_ptr()), cvb_dev.numel(), C.c_void_p(shared_map.data_ptr()),
+                                    shared_map.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    cache.cached_vertices = T(cv_b)
+    cache.cached_features = T(x[cv_b].copy())
+    cache._vertices_dev = cvb_dev
+    cache._features_dev = None
+    run(cv_b)
+
+
 def test_distributed_prefetcher_world_size_1_rccl(fs, graph_a):
     """The RCCL exchange path end to end with one rank (all_to_all_single with itself): the assembled
     x must equal x[n_id] (transferers.py:479-484 identity)."""
