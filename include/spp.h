@@ -163,6 +163,11 @@ typedef struct spp_mfg_out {
   int64_t* perm;                  /* int64[U]: perm_partition_to_mfg (:1085, :1246-1252)           */
 } spp_mfg_out;
 
+/* rowptr_dev / col_dev must stay valid AND unchanged for the sampler's lifetime: an int32 copy of the
+ * neighbour array and a row-stub table (degree, row start and first neighbours of every node in one
+ * 128-byte record; SPP_ROW_STUBS=0 disables it, it is skipped when HBM is short) are derived from them
+ * once and shared by the samplers created over the same arrays.  The cache map of a spp_partition_cfg may
+ * be rewritten between Sessions (its membership bits are rebuilt by spp_session_create). */
 spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
 void spp_sampler_destroy(spp_sampler* s);
 /* bytes of HBM workspace held by the sampler (all slots) */
