@@ -1547,13 +1547,30 @@ struct ExportSegs {
   int64_t start[2 * SPP_MAX_HOPS + 5];
 };
 
+// Segment by segment (uniform pointers: the segment's base addresses stay in scalar registers), four
+// elements per thread and round with their loads issued together.  The earlier form searched the segment
+// of every element and fetched its two pointers from the argument block -- three dependent loads before
+// the element's own, one element per thread and round.
 __device__ __forceinline__ void export_body(const ExportSegs& g, int64_t vblock, int64_t nvblocks) {
-  const int64_t total = g.start[g.n];
-  for (int64_t i = vblock * kNT + threadIdx.x; i < total; i += nvblocks * kNT) {
-    int sgi = 0;
-    while (sgi + 1 < g.n && i >= g.start[sgi + 1]) ++sgi;
-    const int64_t k = i - g.start[sgi];
-    g.dst[sgi][k] = (int64_t)g.src[sgi][k];
+  const int64_t tid = vblock * kNT + threadIdx.x;
+  const int64_t nthreads = nvblocks * kNT;
+  for (int sgi = 0; sgi < g.n; ++sgi) {
+    const int64_t len = g.start[sgi + 1] - g.start[sgi];
+    const int32_t* __restrict__ src = g.src[sgi];
+    int64_t* __restrict__ dst = g.dst[sgi];
+    for (int64_t k0 = tid; k0 < len; k0 += 4 * nthreads) {
+      int32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + u * nthreads;
+        v[u] = src[k < len ? k : len - 1];  // clamped, not predicated
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t k = k0 + u * nthreads;
+        if (k < len) dst[k] = (int64_t)v[u];
+      }
+    }
   }
 }
 
