@@ -163,6 +163,69 @@ def test_sampler_fast_path_golden_graph(lib, graph_a, sizes):
         s.close()
 
 
+def test_standalone_sampler_with_cached_partition(lib, graph_a):
+    """spp_sampler_sample / wait / export with ownership bucketing and a cache, WITHOUT a Session: nobody built
+    the cache membership bits, the bucketing kernels fall back to the map itself."""
+    from oracle import oracle as orc
+    from salient_plusplus_amd import _native as nat
+    rowptr, col, idx = graph_a["rowptr"], graph_a["col"], graph_a["idx"]
+    n = rowptr.shape[0] - 1
+    Pn, rank, sizes = 4, 2, [15, 10, 5]
+    offs = np.array([0, 700, 1500, 2100, n], dtype=np.int64)
+    rng = np.random.default_rng(5)
+    remote = np.setdiff1d(np.arange(n), np.arange(offs[rank], offs[rank + 1]))
+    cv = np.sort(rng.choice(remote, size=250, replace=False)).astype(np.int64)
+    cmap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    d_cv = dev(cv)
+    check(lib, lib.spp_cache_build_map(P(d_cv), d_cv.numel(), P(cmap), n, None))
+    torch.cuda.synchronize()
+    d_rowptr, d_col = dev(rowptr), dev(col)
+    cfg = nat.SamplerCfg()
+    cfg.rowptr_dev, cfg.col_dev = d_rowptr.data_ptr(), d_col.data_ptr()
+    cfg.num_nodes, cfg.nnz, cfg.num_hops = n, col.shape[0], len(sizes)
+    for i, f in enumerate(sizes):
+        cfg.sizes[i] = f
+    cfg.max_batch, cfg.num_slots, cfg.device = 64, 2, 0
+    cfg.part.num_parts, cfg.part.rank = Pn, rank
+    for k in range(Pn + 1):
+        cfg.part.offsets[k] = int(offs[k])
+    cfg.part.use_cache, cfg.part.cache_map_dev, cfg.part.cache_map_len = 1, cmap.data_ptr(), n
+    h = C.c_void_p()
+    check(lib, lib.spp_sampler_create(C.byref(cfg), C.byref(h)))
+    try:
+        ocache = orc.Cache(cv, n)
+        for (start, stop) in [(0, 64), (128, 192)]:
+            d_seeds = dev(np.asarray(idx[start:stop], dtype=np.int64))
+            check(lib, lib.spp_sampler_sample(h, 0, P(d_seeds), d_seeds.numel(), orc.batch_seed(stop), 0, None))
+            cnt = nat.MfgCounts()
+            check(lib, lib.spp_sampler_wait(h, 0, C.byref(cnt)))
+            m = orc.sample_batch(rowptr, col, idx, start, stop, sizes)
+            want = orc.partition_batch(m.n_id, offs, rank, ocache, 0)
+            pc = [int(cnt.part_counts[k]) for k in range(Pn + 1)]
+            assert pc[:Pn] == [len(w) for w in want.partition_nids] and pc[Pn] == len(want.cached_nids)
+            out = nat.MfgOut()
+            U = int(cnt.num_nodes)
+            n_id = torch.empty(U, dtype=torch.int64, device="cuda")
+            parts = torch.empty(max(1, sum(pc[:Pn])), dtype=torch.int64, device="cuda")
+            cached = torch.empty(max(1, pc[Pn]), dtype=torch.int64, device="cuda")
+            perm = torch.empty(U, dtype=torch.int64, device="cuda")
+            keep = []
+            out.n_id, out.parts, out.cached, out.perm = n_id.data_ptr(), parts.data_ptr(), cached.data_ptr(), perm.data_ptr()
+            for k in range(len(sizes)):
+                rp = torch.empty(cnt.T[k] + 1, dtype=torch.int64, device="cuda")
+                cl = torch.empty(max(1, cnt.E[k]), dtype=torch.int64, device="cuda")
+                out.rowptr[k], out.col[k] = rp.data_ptr(), cl.data_ptr()
+                keep += [rp, cl]
+            check(lib, lib.spp_sampler_export(h, 0, C.byref(out), None))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(n_id.cpu().numpy(), m.n_id)
+            np.testing.assert_array_equal(parts.cpu().numpy()[:sum(pc[:Pn])], np.concatenate(want.partition_nids))
+            np.testing.assert_array_equal(cached.cpu().numpy()[:pc[Pn]], want.cached_nids)
+            np.testing.assert_array_equal(perm.cpu().numpy(), want.perm_partition_to_mfg)
+    finally:
+        lib.spp_sampler_destroy(h)
+
+
 @pytest.mark.parametrize("sizes", [[-1], [3, -1], [-1, 2], [40, 2], [33]])
 def test_sampler_generic_path(lib, graph_a, sizes):
     from oracle import oracle as orc
