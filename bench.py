@@ -517,11 +517,19 @@ def main():
     for _w in range(R):
         edges = nodes = 0
         t0 = time.perf_counter()
+        step_t = [] if os.environ.get("SPP_BENCH_STEP_TIMES") == "1" and _w in (2, 3) else None
         for _ in range(a.steps):
+            ts = time.perf_counter()
             b = feeder.next()
             edges += count_edges(b)
             nodes += b.x.size(0)
+            if step_t is not None:
+                step_t.append((time.perf_counter() - ts) * 1e6)
+        ts = time.perf_counter()
         torch.cuda.synchronize()
+        if step_t is not None:                    # diagnostic: host time of every step of a window, and of its closing synchronize
+            print(f"[bench] window {_w}: host us per step " + " ".join(f"{v:.0f}" for v in step_t) +
+                  f" | synchronize {(time.perf_counter() - ts) * 1e6:.0f}", file=sys.stderr, flush=True)
         if distributed:
             feeder.quiesce()
             dist.barrier()

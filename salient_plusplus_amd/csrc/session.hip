@@ -36,6 +36,7 @@
 #include <string>
 #include <thread>
 #include <utility>
+#include <tuple>
 #include <vector>
 
 #include "exchange_internal.h"
@@ -241,6 +242,29 @@ static spp_status launch_group_chain(spp_session* s, int64_t g) {
 }
 
 // Launcher thread body: keep chains in flight for up to num_sets groups beyond the ones fully consumed.
+// SPP_TRACE_LAUNCHER=1: host timestamps (us since the first) of "chain g enqueue begin/end" and of the consumer's
+// "need group g" / "got group g", printed by spp_session_destroy -- who waits for whom
+static bool trace_on() {
+  static const bool on = getenv("SPP_TRACE_LAUNCHER") && atoi(getenv("SPP_TRACE_LAUNCHER")) != 0;
+  return on;
+}
+static std::mutex g_trace_mu;
+static std::vector<std::tuple<long long, char, long long>> g_trace;
+static void trace_ev(char what, long long g) {
+  if (!trace_on()) return;
+  const long long t = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.emplace_back(t, what, g);
+}
+static void trace_dump() {
+  if (!trace_on()) return;
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  if (g_trace.empty()) return;
+  const long long t0 = std::get<0>(g_trace.front());
+  for (auto& e : g_trace) fprintf(stderr, "[spp trace] %lld %c %lld\n", std::get<0>(e) - t0, std::get<1>(e), std::get<2>(e));
+  g_trace.clear();
+}
+
 static void launcher_main(spp_session* s) {
   (void)hipSetDevice(s->cfg.device);
   std::unique_lock<std::mutex> lk(s->mu);
@@ -252,7 +276,9 @@ static void launcher_main(spp_session* s) {
     if (s->stop) return;
     const int64_t g = s->chain_launched;
     lk.unlock();
+    trace_ev('L', g);
     const spp_status rc = launch_group_chain(s, g);  // touches only slots of group g's slot-set
+    trace_ev('l', g);
     lk.lock();
     if (rc != SPP_OK) {
       s->launch_rc = rc;
@@ -671,6 +697,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 }
 
 extern "C" void spp_session_destroy(spp_session* s) {
+  trace_dump();
   if (!s) return;
   if (s->launcher_running || s->exchanger_running) {
     {
@@ -764,6 +791,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   const int64_t g = b / s->G;
   const int32_t slot = (int32_t)((g % s->num_sets) * s->G + b % s->G);
   const auto t0 = std::chrono::steady_clock::now();
+  if (b % s->G == 0) trace_ev('N', g);
   spp_status rc = wait_group_launched(s, g);
   if (rc == SPP_OK && s->tr && s->issue_on_consumer)
     // own group now; the next one from mid-group on -- but only when a second slot-set exists: with one
@@ -787,6 +815,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
     }
   }
   if (rc != SPP_OK) return rc;
+  if (b % s->G == 0) trace_ev('G', g);
   out->batch_index = b;
   out->start = s->ranges[(size_t)b].first;
   out->stop = s->ranges[(size_t)b].second;

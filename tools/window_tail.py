@@ -27,3 +27,54 @@ for w, nxt in zip(wins[-9:-1], wins[-8:]):
 print(f"{'deliveries span us':>20s} {'chain tail us':>14s} {'window (to next) us':>20s}")
 for a, b, c in rows:
     print(f"{a:20.0f} {b:14.0f} {c:20.0f}")
+
+# detail of the last complete window: every delivery (start offset, duration) and the sampling kernels' busy spans
+if len(wins) >= 2:
+    w, nxt = wins[-2], wins[-1]
+    t0, t_next = w[0][0], nxt[0][0]
+    print("\nlast complete window, delivery kernels (start us, duration us):")
+    print("  " + "  ".join(f"{(s - t0) / 1e3:.0f}+{(e - s) / 1e3:.0f}" for s, e in w))
+    spans = []
+    for s, e in ch:
+        if e < t0 or s > t_next:
+            continue
+        if spans and s <= spans[-1][1] + 2000:
+            spans[-1][1] = max(spans[-1][1], e)
+        else:
+            spans.append([s, e])
+    print("sampling kernels busy (start us .. end us, gaps < 2 us merged):")
+    print("  " + "  ".join(f"{(s - t0) / 1e3:.0f}..{(e - t0) / 1e3:.0f}" for s, e in spans))
+
+# chain starts (k_seed_init launches) and ends (last k_hop_rows / k_gpart_scatter before the next start) per queue
+if len(wins) >= 3:
+    w0, w1 = wins[-3], wins[-1]
+    ta, tb = w0[0][0], w1[-1][1]
+    t0 = wins[-2][0][0]
+    ev = []
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"]
+        if "spp::" not in n or "k_deliver" in n:
+            continue
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if e < ta or s > tb:
+            continue
+        ev.append((s, e, r.get("Queue_Id", "?"), n.split("(")[0].replace("void ", "").replace("spp::", "")))
+    ev.sort()
+    print("\nchains around the last complete window (queue: start .. end us relative to its first delivery; one per k_seed_init):")
+    by_q = {}
+    for s, e, q, n in ev:
+        by_q.setdefault(q, []).append((s, e, n))
+    for q, lst in by_q.items():
+        cur = None
+        out = []
+        for s, e, n in lst:
+            if n.startswith("k_seed_init"):
+                if cur:
+                    out.append(cur)
+                cur = [s, e]
+            elif cur:
+                cur[1] = max(cur[1], e)
+        if cur:
+            out.append(cur)
+        print(f"  queue {q}: " + "  ".join(f"{(s - t0) / 1e3:.0f}..{(e - t0) / 1e3:.0f}" for s, e in out))
+    print("deliveries of the three windows (start us): " + " ".join(f"{(s - t0) / 1e3:.0f}" for s, e in wins[-3] + wins[-2] + wins[-1]))
