@@ -1302,7 +1302,22 @@ struct PartDev {
   // start: N/8 bytes stay cache resident (14 MB for 111 M nodes), where a 4-byte lookup per remote node
   // in the 444 MB map was one HBM line each -- more lines per batch than the neighbour reads
   const uint32_t* cache_bits;
+  // one bit per 64-node word of cache_bits (set: the word is not zero) -- N/512 bytes, L2 resident: with a cache
+  // of ~1 % of the nodes about half of the 64-node words are empty, and their lookups stop here
+  const uint32_t* cache_coarse;
 };
+
+__global__ __launch_bounds__(256) void k_cache_coarse(const unsigned long long* __restrict__ bits64, int64_t nwords,
+                                                      unsigned long long* __restrict__ coarse64) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t nc = (nwords + 63) / 64;
+  for (int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) / kWave; c < nc; c += (int64_t)gridDim.x * (256 / kWave)) {
+    const int64_t w = c * 64 + lane;
+    const unsigned long long v = bits64[w < nwords ? w : nwords - 1];
+    const unsigned long long mask = __ballot(w < nwords && v != 0ull);
+    if (lane == 0) coarse64[c] = mask;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_cache_bits(const int32_t* __restrict__ map, int64_t len,
                                                     unsigned long long* __restrict__ bits64) {
@@ -1350,6 +1365,13 @@ __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__
   for (int k = threadIdx.x; k <= a.P; k += kNT) cnt[k] = 0;
   // round trip 2: the cache map entries of the remote nodes (others read entry 0: no predicate on the load)
   int32_t cm[kPartRounds];
+  uint32_t cw[kPartRounds];
+  bool look_r[kPartRounds];
+#pragma unroll
+  for (int r = 0; r < kPartRounds; ++r) {
+    cw[r] = 0u;
+    look_r[r] = false;
+  }
 #pragma unroll
   for (int r = 0; r < kPartRounds; ++r) {
     const int64_t i = (int64_t)bx_ * kPartSpan + r * kNT + threadIdx.x;
@@ -1357,12 +1379,23 @@ __global__ __launch_bounds__(kNT) void k_gpart_hist(const SlotPtrs* __restrict__
     const int64_t vv = v[r];
     const bool look = a.use_cache && vv >= 0 && vv < a.cache_len && !(vv >= a.off.v[a.rank] && vv < a.off.v[a.rank + 1]);
     if (a.cache_bits) {
-      const uint32_t w = a.cache_bits[look ? (vv >> 5) : 0];
-      cm[r] = (look && ((w >> (vv & 31)) & 1u)) ? 0 : -1;  // only the sign is used: >= 0 = cached
+      look_r[r] = look;
+      cw[r] = a.cache_coarse[look ? (vv >> 11) : 0];  // coarse level first (all four in flight)
     } else {  // no Session built the bits (stand-alone spp_sampler_sample): the map itself
       cm[r] = a.use_cache ? a.cache_map[look ? vv : 0] : -1;
       if (!look) cm[r] = -1;
     }
+  }
+  if (a.cache_bits) {  // fine level, only where the coarse bit is set (the others read word 0: no predicate on the load)
+    uint32_t fw[kPartRounds];
+#pragma unroll
+    for (int r = 0; r < kPartRounds; ++r) {
+      const int64_t vv = v[r];
+      look_r[r] = look_r[r] && ((cw[r] >> ((vv >> 6) & 31)) & 1u);
+      fw[r] = a.cache_bits[look_r[r] ? (vv >> 5) : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < kPartRounds; ++r) cm[r] = (look_r[r] && ((fw[r] >> (v[r] & 31)) & 1u)) ? 0 : -1;  // only the sign is used
   }
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1);
@@ -2546,13 +2579,17 @@ spp_status sampler_refresh_cache_bits(spp_sampler* s, hipStream_t st, hipEvent_t
   const int64_t nwords = (s->part.cache_len + 63) / 64;
   if (!s->cache_bits) {
     SPP_HIP_TRY(hipSetDevice(s->cfg.device));
-    SPP_HIP_TRY(hipMalloc((void**)&s->cache_bits, sizeof(unsigned long long) * (size_t)nwords));
-    s->bytes += (int64_t)sizeof(unsigned long long) * nwords;
+    const int64_t ncoarse = (nwords + 63) / 64;  // the coarse level lives behind the fine one
+    SPP_HIP_TRY(hipMalloc((void**)&s->cache_bits, sizeof(unsigned long long) * (size_t)(nwords + ncoarse)));
+    s->bytes += (int64_t)sizeof(unsigned long long) * (nwords + ncoarse);
     s->part.cache_bits = reinterpret_cast<const uint32_t*>(s->cache_bits);
+    s->part.cache_coarse = reinterpret_cast<const uint32_t*>(s->cache_bits + nwords);
   }
   if (!s->cache_bits_ready) SPP_HIP_TRY(hipEventCreateWithFlags(&s->cache_bits_ready, hipEventDisableTiming));
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(nwords, 256 / kWave), 256 * 16);
   hipLaunchKernelGGL(k_cache_bits, dim3(grid), dim3(256), 0, st, s->part.cache_map, s->part.cache_len, s->cache_bits);
+  hipLaunchKernelGGL(k_cache_coarse, dim3((unsigned)std::min<int64_t>(ceil_div(ceil_div(nwords, 64), 256 / kWave), 1024)), dim3(256),
+                     0, st, s->cache_bits, nwords, s->cache_bits + nwords);
   SPP_HIP_TRY(hipGetLastError());
   SPP_HIP_TRY(hipEventRecord(s->cache_bits_ready, st));
   *ready = s->cache_bits_ready;
