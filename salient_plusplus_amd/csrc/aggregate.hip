@@ -501,6 +501,10 @@ __global__ __launch_bounds__(kAggNT) void k_gat_bwd(const int64_t* __restrict__ 
 __device__ __forceinline__ f4 load4v(const float* p) { return load4(p); }
 
 // a_src[j] = x_j . v_src  (all S rows);  a_dst[j] = x_j . v_dst  (the first T rows: the targets)
+// A group of lpr lanes takes kDotRows consecutive rows; their loads are issued back to back (row index clamped,
+// not predicated: with one row per group and a predicate the kernel had ONE load in flight per lane and ran
+// at a third of the HBM rate).
+constexpr int kDotRows = 8;
 template <typename Tin>
 __global__ __launch_bounds__(kAggNT) void k_rowdot2(const Tin* __restrict__ x, int64_t x_stride, int64_t S, int64_t T,
                                                     int64_t K, const float* __restrict__ v_src,
@@ -508,45 +512,65 @@ __global__ __launch_bounds__(kAggNT) void k_rowdot2(const Tin* __restrict__ x, i
                                                     float* __restrict__ a_src, float* __restrict__ a_dst) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
-  const int64_t j = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
-  float ds = 0.f, dd = 0.f;
-  if (j < S) {
-    for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpr * 4) {
-      const f4 xv = load4(x + j * x_stride + c);
-      const f4 vs = load4v(v_src + c);
-      ds += xv.x * vs.x + xv.y * vs.y + xv.z * vs.z + xv.w * vs.w;
-      if (j < T) {
-        const f4 vd = load4v(v_dst + c);
-        dd += xv.x * vd.x + xv.y * vd.y + xv.z * vd.z + xv.w * vd.w;
-      }
+  const int64_t j0 = (((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2) * kDotRows;
+  if (j0 >= S) return;  // whole groups leave together (the shuffles below stay inside a group)
+  float ds[kDotRows], dd[kDotRows];
+#pragma unroll
+  for (int u = 0; u < kDotRows; ++u) ds[u] = dd[u] = 0.f;
+  for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpr * 4) {
+    f4 xv[kDotRows];
+#pragma unroll
+    for (int u = 0; u < kDotRows; ++u) {
+      const int64_t j = j0 + u < S ? j0 + u : S - 1;
+      xv[u] = load4(x + j * x_stride + c);
+    }
+    const f4 vs = load4v(v_src + c), vd = load4v(v_dst + c);
+#pragma unroll
+    for (int u = 0; u < kDotRows; ++u) {
+      ds[u] += xv[u].x * vs.x + xv[u].y * vs.y + xv[u].z * vs.z + xv[u].w * vs.w;
+      dd[u] += xv[u].x * vd.x + xv[u].y * vd.y + xv[u].z * vd.z + xv[u].w * vd.w;
     }
   }
-  for (int d = lpr >> 1; d >= 1; d >>= 1) {  // the lpr lanes of a row are consecutive lanes of one wavefront
-    ds += __shfl_xor(ds, d, kWave);
-    dd += __shfl_xor(dd, d, kWave);
+#pragma unroll
+  for (int u = 0; u < kDotRows; ++u) {
+    for (int d = lpr >> 1; d >= 1; d >>= 1) {  // the lpr lanes of a row are consecutive lanes of one wavefront
+      ds[u] += __shfl_xor(ds[u], d, kWave);
+      dd[u] += __shfl_xor(dd[u], d, kWave);
+    }
   }
-  if (j < S && lane == 0) {
-    a_src[j] = ds;
-    if (j < T) a_dst[j] = dd;
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < kDotRows; ++u) {
+      const int64_t j = j0 + u;
+      if (j < S) {
+        a_src[j] = ds[u];
+        if (j < T) a_dst[j] = dd[u];
+      }
+    }
   }
 }
 
 // out_src[c] += sum_j w_src[j] x[j,c] over all rows; out_dst[c] += sum_{j<T} w_dst[j] x[j,c]   (out zeroed by the caller)
+// (1024 threads and 4096 rows per workgroup: every workgroup ends in K atomics onto the SAME K addresses, and with
+// 256-thread / 1024-row workgroups those 924 x 256 same-address adds were most of the kernel's time)
+constexpr int kColsumNT = 1024;
 template <typename Tin>
-__global__ __launch_bounds__(kAggNT) void k_colsum2(const Tin* __restrict__ x, int64_t x_stride, int64_t S, int64_t T,
-                                                    int64_t K, const float* __restrict__ w_src,
-                                                    const float* __restrict__ w_dst, int64_t rows_per_wg,
-                                                    float* __restrict__ out_src, float* __restrict__ out_dst) {
-  __shared__ float red[2][kAggNT][4];
-  const int groups = (int)(K / 4);              // threads that share a row (K/4 <= kAggNT)
+__global__ __launch_bounds__(kColsumNT) void k_colsum2(const Tin* __restrict__ x, int64_t x_stride, int64_t S, int64_t T,
+                                                       int64_t K, const float* __restrict__ w_src,
+                                                       const float* __restrict__ w_dst, int64_t rows_per_wg,
+                                                       float* __restrict__ out_src, float* __restrict__ out_dst) {
+  __shared__ float red[2][kColsumNT][4];
+  const int groups = (int)(K / 4);              // threads that share a row (K/4 <= kColsumNT)
   const int cg = threadIdx.x % groups;          // this thread's 4 columns
-  const int rsub = threadIdx.x / groups, rstep = kAggNT / groups;
+  const int rsub = threadIdx.x / groups, rstep = kColsumNT / groups;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t r1 = r0 + rows_per_wg < S ? r0 + rows_per_wg : S;
   f4 as = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f};
   if (rsub < rstep) {
     int64_t j = r0 + rsub;
-    for (; j + 3 * rstep < r1; j += 4 * rstep) {  // four independent rows in flight
+    const int64_t tlast = T > 0 ? T - 1 : 0;
+    const float* __restrict__ wdp = T > 0 ? w_dst : w_src;  // (w_dst may be NULL without targets)
+    for (; j + 3 * rstep < r1; j += 4 * rstep) {  // four independent rows in flight, no predicate on a load (eight: slower)
       f4 xv[4];
       float ws[4], wd[4];
 #pragma unroll
@@ -554,7 +578,8 @@ __global__ __launch_bounds__(kAggNT) void k_colsum2(const Tin* __restrict__ x, i
         const int64_t ju = j + u * rstep;
         xv[u] = load4(x + ju * x_stride + (int64_t)cg * 4);
         ws[u] = w_src[ju];
-        wd[u] = ju < T ? w_dst[ju] : 0.f;
+        wd[u] = wdp[ju < T ? ju : tlast];
+        if (ju >= T) wd[u] = 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -733,7 +758,7 @@ extern "C" spp_status spp_gat_logits(const void* x_dev, int32_t x_is_half, int64
                   reinterpret_cast<uintptr_t>(v_src_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(v_dst_dev) % 16 == 0,
               "spp_gat_logits: NULL or unaligned buffer");
   const int lpr_log2 = lanes_log2(K / 4);
-  const unsigned grid = (unsigned)ceil_div(num_sources << lpr_log2, kAggNT);
+  const unsigned grid = (unsigned)ceil_div(ceil_div(num_sources, kDotRows) << lpr_log2, kAggNT);
   if (x_is_half)
     hipLaunchKernelGGL(k_rowdot2<__half>, dim3(grid), dim3(kAggNT), 0, as_stream(stream), static_cast<const __half*>(x_dev),
                        x_stride_elems, num_sources, num_targets, K, v_src_dev, v_dst_dev, lpr_log2, a_src_dev, a_dst_dev);
@@ -756,14 +781,16 @@ extern "C" spp_status spp_gat_logits_backward(const void* x_dev, int32_t x_is_ha
   SPP_HIP_TRY(hipMemsetAsync(grad_v_dst_dev, 0, sizeof(float) * (size_t)K, st));
   if (num_sources == 0) return SPP_OK;
   SPP_REQUIRE(grad_a_src_dev && (grad_a_dst_dev || num_targets == 0), "spp_gat_logits_backward: NULL input");
-  const int64_t rows_per_wg = 1024;  // 4 rows in flight per lane; K atomics onto the same K addresses per workgroup
+  // 4 rows in flight per lane; K atomics onto the same K addresses per workgroup: about one workgroup per CU,
+  // between 1024 and 4096 rows each
+  const int64_t rows_per_wg = std::max<int64_t>(1024, std::min<int64_t>(4096, ceil_div(num_sources, 256)));
   const unsigned grid = (unsigned)ceil_div(num_sources, rows_per_wg);
   if (x_is_half)
-    hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
+    hipLaunchKernelGGL(k_colsum2<__half>, dim3(grid), dim3(kColsumNT), 0, st, static_cast<const __half*>(x_dev), x_stride_elems,
                        num_sources, num_targets, K, grad_a_src_dev, grad_a_dst_dev, rows_per_wg, grad_v_src_dev,
                        grad_v_dst_dev);
   else
-    hipLaunchKernelGGL(k_colsum2<float>, dim3(grid), dim3(kAggNT), 0, st, static_cast<const float*>(x_dev), x_stride_elems,
+    hipLaunchKernelGGL(k_colsum2<float>, dim3(grid), dim3(kColsumNT), 0, st, static_cast<const float*>(x_dev), x_stride_elems,
                        num_sources, num_targets, K, grad_a_src_dev, grad_a_dst_dev, rows_per_wg, grad_v_src_dev,
                        grad_v_dst_dev);
   SPP_HIP_TRY(hipGetLastError());
