@@ -633,20 +633,36 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_fwd(const int64_t* __restric
     const bool has = c < K;
     f4 acc = has ? load4(x + t * x_stride + c) : f4{0.f, 0.f, 0.f, 0.f};
     float mm = self, ss = 1.f;
-    for (int64_t k = b; k < e; ++k) {
-      const int64_t j = col[k];
-      if (j == t) continue;  // set_diag drops existing diagonal entries
-      const float sc = lrelu(a_src[j] + ad, slope);
-      const f4 xv = has ? load4(x + j * x_stride + c) : f4{0.f, 0.f, 0.f, 0.f};
-      if (sc > mm) {
-        const float r = __expf(mm - sc);
-        acc.x *= r; acc.y *= r; acc.z *= r; acc.w *= r;
-        ss *= r;
-        mm = sc;
+    // kNb neighbours per round: their ids, then their logits and rows, each issued back to back (clamped
+    // indices, no predicated load); the online softmax then runs over registers.  One neighbour at a time
+    // was two dependent round trips per edge.
+    constexpr int kNb = 4;
+    const int64_t cc = has ? c : 0;
+    for (int64_t k0 = b; k0 < e; k0 += kNb) {
+      int64_t j[kNb];
+#pragma unroll
+      for (int u = 0; u < kNb; ++u) j[u] = col[k0 + u < e ? k0 + u : e - 1];
+      float as[kNb];
+      f4 xv[kNb];
+#pragma unroll
+      for (int u = 0; u < kNb; ++u) {
+        as[u] = a_src[j[u]];
+        xv[u] = load4(x + j[u] * x_stride + cc);
       }
-      const float w = __expf(sc - mm);
-      ss += w;
-      acc.x += w * xv.x; acc.y += w * xv.y; acc.z += w * xv.z; acc.w += w * xv.w;
+#pragma unroll
+      for (int u = 0; u < kNb; ++u) {
+        if (k0 + u >= e || j[u] == t) continue;  // set_diag drops existing diagonal entries
+        const float sc = lrelu(as[u] + ad, slope);
+        if (sc > mm) {
+          const float r = __expf(mm - sc);
+          acc.x *= r; acc.y *= r; acc.z *= r; acc.w *= r;
+          ss *= r;
+          mm = sc;
+        }
+        const float w = __expf(sc - mm);
+        ss += w;
+        acc.x += w * xv[u].x; acc.y += w * xv[u].y; acc.z += w * xv[u].z; acc.w += w * xv[u].w;
+      }
     }
     if (has) {
       const float inv = 1.f / ss;
