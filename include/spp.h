@@ -443,6 +443,16 @@ spp_status spp_relu_dropout_forward(const float* x_dev, int64_t n, float p, int3
                                     float* y_dev, void* stream);
 spp_status spp_relu_dropout_backward(const float* grad_dev, const float* y_dev, int64_t n, float scale,
                                      float* grad_x_dev, void* stream);
+/* The same two steps without the activated copy: spp_sage_operand_forward_act builds [mean | x_target] of
+ * relu_dropout(x) from the PRE-activation x (fp32, dense rows, F % 4 == 0), applying the activation to every
+ * row as it is loaded -- the values spp_relu_dropout_forward(x, n = S*F, p, training, seed) would have
+ * written -- and spp_relu_dropout_backward_pre recomputes the mask from x and the same (p, training, seed):
+ * grad_x = grad / (1-p) where x > 0 and the element was kept (n % 4 == 0). */
+spp_status spp_sage_operand_forward_act(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                        const float* x_dev, int64_t F, float* out_dev, int64_t out_stride_elems,
+                                        float p, int32_t training, uint64_t seed, void* stream);
+spp_status spp_relu_dropout_backward_pre(const float* grad_dev, const float* z_dev, int64_t n, float p,
+                                         int32_t training, uint64_t seed, float* grad_x_dev, void* stream);
 
 /* GATConv(heads=1) message passing over one MFG hop (driver/models.py:195-231):
  *   e_ij = leaky_relu(a_src[j] + a_dst[i], negative_slope) over row i without its diagonal entry plus

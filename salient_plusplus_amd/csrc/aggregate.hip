@@ -34,34 +34,69 @@ __device__ __forceinline__ f4 load4(const __half* p) {
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const __half* p) { return __half2float(*p); }
 
+// ---- ReLU + dropout (driver/models.py:47-48: x = F.relu(x); x = F.dropout(x, p=0.5)) ----
+// keep / drop from a counter-based generator: element i of the call with `seed` is kept iff
+// hash(seed, i) < (1 - p) * 2^32; the output is relu(x) / (1 - p) where kept, 0 elsewhere.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct ActArgs {
+  uint32_t keep_thr;
+  float scale;
+  uint64_t seed;
+  int32_t training;
+};
+// the activation of the four elements 4*i4 .. 4*i4+3 of a dense array, exactly as k_relu_dropout_fwd computes it
+__device__ __forceinline__ f4 relu_dropout4(f4 v, int64_t i4, const ActArgs& a) {
+  if (!a.training) return {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+  const uint64_t r0 = mix64(a.seed + 2ull * (uint64_t)i4 * 0x9E3779B97F4A7C15ull);
+  const uint64_t r1 = mix64(a.seed + (2ull * (uint64_t)i4 + 1ull) * 0x9E3779B97F4A7C15ull);
+  f4 o;
+  o.x = (v.x > 0.f && (uint32_t)r0 < a.keep_thr) ? v.x * a.scale : 0.f;
+  o.y = (v.y > 0.f && (uint32_t)(r0 >> 32) < a.keep_thr) ? v.y * a.scale : 0.f;
+  o.z = (v.z > 0.f && (uint32_t)r1 < a.keep_thr) ? v.z * a.scale : 0.f;
+  o.w = (v.w > 0.f && (uint32_t)(r1 >> 32) < a.keep_thr) ? v.w * a.scale : 0.f;
+  return o;
+}
+
 // VEC4: F % 4 == 0 and rows 16-B (fp32) / 8-B (fp16) aligned
-template <typename Tin, bool VEC4>
+// kAct (fp32, VEC4, dense rows: x_stride == F): x is a PRE-activation; relu + dropout are applied to every row
+// as it is loaded -- the same values a k_relu_dropout_fwd pass over x would have produced (same generator,
+// same element indices), without the pass.
+template <typename Tin, bool VEC4, bool kAct = false>
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
                                                          const Tin* __restrict__ x, int64_t x_stride, int64_t F,
                                                          int lpr_log2, float* __restrict__ out, int64_t out_stride,
-                                                         int concat_target) {
+                                                         int concat_target, ActArgs act) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
   if (t >= T) return;
   const int64_t b = rowptr[t], e = rowptr[t + 1];
   const float inv = 1.0f / (float)(e > b ? e - b : 1);
+  auto row4 = [&](int64_t j, int64_t c) {  // four columns of row j (activated on load with kAct)
+    f4 v = load4(x + j * x_stride + c);
+    if constexpr (kAct) v = relu_dropout4(v, (j * x_stride + c) >> 2, act);
+    return v;
+  };
   if (VEC4) {
     for (int64_t c = (int64_t)lane * 4; c < F; c += (int64_t)lpr * 4) {
       if (concat_target) {  // [mean | x_target]: the target's own row (targets are the first rows of x), as fp32
-        const f4 own = load4(x + t * x_stride + c);
+        const f4 own = row4(t, c);
         *reinterpret_cast<float4*>(out + t * out_stride + F + c) = make_float4(own.x, own.y, own.z, own.w);
       }
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       int64_t k = b;
       for (; k + 1 < e; k += 2) {  // two independent rows in flight
-        const f4 v0 = load4(x + col[k] * x_stride + c), v1 = load4(x + col[k + 1] * x_stride + c);
+        const f4 v0 = row4(col[k], c), v1 = row4(col[k + 1], c);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
       }
       if (k < e) {
-        const f4 v0 = load4(x + col[k] * x_stride + c);
+        const f4 v0 = row4(col[k], c);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
       }
       *reinterpret_cast<float4*>(out + t * out_stride + c) =
@@ -108,16 +143,8 @@ __global__ __launch_bounds__(kAggNT) void k_grad_init(const float* __restrict__ 
   }
 }
 
-// ---- ReLU + dropout in one pass (driver/models.py:47-48: x = F.relu(x); x = F.dropout(x, p=0.5)) ----
-// keep / drop from a counter-based generator: element i of the call with `seed` is kept iff
-// hash(seed, i) < (1 - p) * 2^32; the output is relu(x) / (1 - p) where kept, 0 elsewhere.  The backward
-// pass needs no mask: y > 0 exactly where x > 0 and the element was kept.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
+// ---- ReLU + dropout in one pass (the stand-alone form; the SAGE stack applies them on load, see kAct) ----
+// The backward pass needs no mask: y > 0 exactly where x > 0 and the element was kept.
 __global__ __launch_bounds__(kAggNT) void k_relu_dropout_fwd(const float* __restrict__ x, int64_t n, uint32_t keep_thr,
                                                              float scale, uint64_t seed, int training,
                                                              float* __restrict__ y) {
@@ -156,6 +183,20 @@ __global__ __launch_bounds__(kAggNT) void k_relu_dropout_bwd(const float* __rest
   }
   const int64_t t = n4 * 4 + threadIdx.x;
   if (blockIdx.x == 0 && t < n) gx[t] = y[t] > 0.f ? g[t] * scale : 0.f;
+}
+
+// the same backward from the PRE-activation z and the generator (no activated copy exists when the forward
+// applied the activation on load): gx = g * scale where z > 0 and the element was kept
+__global__ __launch_bounds__(kAggNT) void k_relu_dropout_bwd_pre(const float* __restrict__ g, const float* __restrict__ z,
+                                                                 int64_t n, ActArgs act, float* __restrict__ gx) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * kAggNT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kAggNT) {
+    const float4 a = reinterpret_cast<const float4*>(g)[i], b = reinterpret_cast<const float4*>(z)[i];
+    const f4 m = relu_dropout4(f4{b.x, b.y, b.z, b.w}, i, act);  // > 0 exactly where z > 0 and kept
+    const float sc = act.training ? act.scale : 1.f;
+    reinterpret_cast<float4*>(gx)[i] = make_float4(m.x > 0.f ? a.x * sc : 0.f, m.y > 0.f ? a.y * sc : 0.f,
+                                                   m.z > 0.f ? a.z * sc : 0.f, m.w > 0.f ? a.w * sc : 0.f);
+  }
 }
 
 // ---- backward of the fused operand by GATHER over the transposed hop ----------------------------
@@ -264,13 +305,55 @@ static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev
 #define SPP_AGG(TIN, V)                                                                                          \
   hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, \
                      static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems,   \
-                     concat_target)
+                     concat_target, ActArgs{})
   if (x_is_half) {
     if (vec) SPP_AGG(__half, true); else SPP_AGG(__half, false);
   } else {
     if (vec) SPP_AGG(float, true); else SPP_AGG(float, false);
   }
 #undef SPP_AGG
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+static ActArgs act_args(float p, int32_t training, uint64_t seed) {
+  const double keep = 1.0 - (double)p;
+  ActArgs a{};
+  a.keep_thr = keep >= 1.0 ? 0xffffffffu : (uint32_t)(keep * 4294967296.0);
+  a.scale = (float)(1.0 / keep);
+  a.seed = seed;
+  a.training = training ? 1 : 0;
+  return a;
+}
+
+// [mean | x_target] of relu_dropout(x) without materialising the activation (see kAct)
+extern "C" spp_status spp_sage_operand_forward_act(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                   const float* x_dev, int64_t F, float* out_dev, int64_t out_stride_elems,
+                                                   float p, int32_t training, uint64_t seed, void* stream) {
+  SPP_REQUIRE(num_targets >= 0 && F >= 0 && p >= 0.f && p < 1.f, "spp_sage_operand_forward_act: bad arguments");
+  if (num_targets == 0 || F == 0) return SPP_OK;
+  SPP_REQUIRE(rowptr_dev && x_dev && out_dev && out_stride_elems >= 2 * F && F % 4 == 0 && out_stride_elems % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(x_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(out_dev) % 16 == 0,
+              "spp_sage_operand_forward_act: needs dense fp32 rows with F %% 4 == 0 and 16-byte aligned buffers");
+  const int lpr_log2 = lanes_log2(F / 4);
+  const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
+  hipLaunchKernelGGL((k_csr_mean_fwd<float, true, true>), dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev,
+                     col_dev, num_targets, x_dev, F, F, lpr_log2, out_dev, out_stride_elems, 1, act_args(p, training, seed));
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_relu_dropout_backward_pre(const float* grad_dev, const float* z_dev, int64_t n, float p,
+                                                    int32_t training, uint64_t seed, float* grad_x_dev, void* stream) {
+  SPP_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, "spp_relu_dropout_backward_pre: bad arguments");
+  if (n == 0) return SPP_OK;
+  SPP_REQUIRE(grad_dev && z_dev && grad_x_dev && n % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(grad_dev) | reinterpret_cast<uintptr_t>(z_dev) |
+                   reinterpret_cast<uintptr_t>(grad_x_dev)) % 16 == 0,
+              "spp_relu_dropout_backward_pre: needs n %% 4 == 0 and 16-byte aligned buffers");
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / 4, kAggNT), 256 * 32));
+  hipLaunchKernelGGL(k_relu_dropout_bwd_pre, dim3(grid), dim3(kAggNT), 0, as_stream(stream), grad_dev, z_dev, n,
+                     act_args(p, training, seed), grad_x_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -249,25 +249,30 @@ class _SageStack(torch.autograd.Function):
         n_layers = len(hops)
         st = _stream()
         h = x
-        operands, acts, wcats = [], [], []
+        operands, acts, wcats, seeds = [], [], [], []
         for i, (rowptr, col, T) in enumerate(hops):
             K = h.size(1)
             A = torch.empty((T, 2 * K), dtype=torch.float32, device=x.device)
-            nat.check(L.spp_sage_operand_forward(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
-                                                 h.stride(0) if h.size(0) > 1 else K, K, _p(A), 2 * K, st))
+            if i == 0:
+                nat.check(L.spp_sage_operand_forward(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
+                                                     h.stride(0) if h.size(0) > 1 else K, K, _p(A), 2 * K, st))
+            else:
+                # h is the previous layer's PRE-activation: ReLU + dropout are applied to its rows as they are
+                # loaded (no separate pass over the activation, which is never materialised)
+                nat.check(L.spp_sage_operand_forward_act(_p(rowptr), _p(col), T, _p(h), K, _p(A), 2 * K, float(p),
+                                                         int(bool(training)), seeds[i - 1], st))
             W = torch.cat([weights[2 * i], weights[2 * i + 1]], dim=1)          # [N, 2K] = [W_l | W_r]
             Z = A @ W.t()
             operands.append(A)
             wcats.append(W)
             if i != n_layers - 1:
-                seed = int(torch.empty((), dtype=torch.int64).random_().item()) if training else 0
-                nat.check(L.spp_relu_dropout_forward(_p(Z), Z.numel(), float(p), int(bool(training)), seed, _p(Z), st))
-                acts.append(Z)                                                  # in place: Z now holds the activation
+                seeds.append(int(torch.empty((), dtype=torch.int64).random_().item()) if training else 0)
+                acts.append(Z)                                                  # the pre-activation
                 h = Z
             else:
                 out = torch.log_softmax(Z, dim=-1)
         ctx.hops = hops
-        ctx.scale = 1.0 / (1.0 - float(p)) if training else 1.0
+        ctx.act = (float(p), int(bool(training)), seeds)
         ctx.saved = (operands, acts, wcats, out)
         ctx.src_rows = [x.size(0)] + [a.size(0) for a in acts]
         return out
@@ -299,7 +304,9 @@ class _SageStack(torch.autograd.Function):
                                                              _p(ws), nbytes, st))
             else:
                 nat.check(L.spp_sage_operand_backward(_p(rowptr), _p(col), T, S, _p(gA), 2 * K, K, _p(gH), st))
-            nat.check(L.spp_relu_dropout_backward(_p(gH), _p(acts[i - 1]), gH.numel(), ctx.scale, _p(gH), st))
+            p_, training_, seeds = ctx.act
+            nat.check(L.spp_relu_dropout_backward_pre(_p(gH), _p(acts[i - 1]), gH.numel(), p_, training_, seeds[i - 1],
+                                                      _p(gH), st))
             gZ = gH
         ctx.saved = None
         return (None, None, None, None, *grads)

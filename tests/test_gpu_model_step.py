@@ -267,11 +267,41 @@ def test_relu_dropout_fused():
     assert 0.24 < kept25 < 0.26, kept25
 
 
+@pytest.mark.parametrize("training", [0, 1])
+def test_activation_on_load_equals_the_separate_pass(training):
+    """spp_sage_operand_forward_act (ReLU + dropout applied to the rows as they are loaded) and
+    spp_relu_dropout_backward_pre (mask recomputed from the pre-activation) give, bit for bit, what the separate
+    pass + the plain operand kernel + the y-based backward give for the same (p, training, seed)."""
+    import ctypes as C
+    from salient_plusplus_amd import _native as nat
+    L = nat.load()
+    T, S, F, p_drop, seed = 1700, 6100, 256, 0.5, 0x1234567890ABCDEF >> 1
+    rowptr, col = _random_hop(T, S, 11, 99)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    z = torch.randn((S, F), device="cuda")
+    y = torch.empty_like(z)
+    nat.check(L.spp_relu_dropout_forward(P(z), z.numel(), p_drop, training, seed, P(y), st))
+    a_ref = torch.empty((T, 2 * F), device="cuda")
+    nat.check(L.spp_sage_operand_forward(P(rowptr), P(col), T, P(y), 0, F, F, P(a_ref), 2 * F, st))
+    a_act = torch.empty((T, 2 * F), device="cuda")
+    nat.check(L.spp_sage_operand_forward_act(P(rowptr), P(col), T, P(z), F, P(a_act), 2 * F, p_drop, training, seed, st))
+    torch.cuda.synchronize()
+    assert torch.equal(a_act, a_ref)
+    g = torch.randn((S, F), device="cuda")
+    gx_ref, gx_pre = torch.empty_like(g), torch.empty_like(g)
+    nat.check(L.spp_relu_dropout_backward(P(g), P(y), g.numel(), 2.0 if training else 1.0, P(gx_ref), st))
+    nat.check(L.spp_relu_dropout_backward_pre(P(g), P(z), g.numel(), p_drop, training, seed, P(gx_pre), st))
+    torch.cuda.synchronize()
+    assert torch.equal(gx_pre, gx_ref)
+
+
 @pytest.mark.parametrize("K,N,dtype", [(128, 256, torch.float16), (256, 64, torch.float32), (100, 47, torch.float32)])
 def test_gat_layer_aggregate_then_project_matches_project_then_aggregate(K, N, dtype):
     """_GatLayer (logits from W^T att, aggregation of the raw rows, projection of the targets only) against
     GATConv's own order of operations written with plain torch ops: forward and every gradient."""
     from salient_plusplus_amd.models import _GatLayer
+    torch.manual_seed(1000 + K)        # the cotangent below comes from the global generator: independent of test order
     T, S = 1500, 6000
     rowptr, col = _random_hop(T, S, 12, K + N)
     col[::13] = torch.repeat_interleave(torch.arange(T, device="cuda"), rowptr[1:] - rowptr[:-1])[::13]   # diagonal entries
@@ -291,7 +321,8 @@ def test_gat_layer_aggregate_then_project_matches_project_then_aggregate(K, N, d
     w = torch.randn((T, N), device="cuda")
     (out_a * w).sum().backward()
     (out_b * w).sum().backward()
+    # (1500-term sums in another association, fp32 atomics: a few 1e-4 absolute on entries of magnitude ~1)
     for a, b in zip(pa, pb):
-        torch.testing.assert_close(a.grad, b.grad, rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(a.grad, b.grad, rtol=2e-3, atol=5e-4)
     if need_gx:
-        torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-3, atol=2e-4)
+        torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-3, atol=5e-4)
