@@ -453,6 +453,13 @@ spp_status spp_sage_operand_forward_act(const int64_t* rowptr_dev, const int64_t
                                         float p, int32_t training, uint64_t seed, void* stream);
 spp_status spp_relu_dropout_backward_pre(const float* grad_dev, const float* z_dev, int64_t n, float p,
                                          int32_t training, uint64_t seed, float* grad_x_dev, void* stream);
+/* spp_sage_operand_backward_gather with spp_relu_dropout_backward_pre applied to every row before it is
+ * stored: grad_x_dev becomes the gradient w.r.t. the pre-activation z_pre_dev (dense fp32 [S, F]). */
+spp_status spp_sage_operand_backward_gather_act(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                int64_t num_sources, int64_t num_edges, const float* grad_out_dev,
+                                                int64_t grad_out_stride_elems, int64_t F, float* grad_x_dev,
+                                                void* workspace_dev, int64_t workspace_bytes, const float* z_pre_dev,
+                                                float p, int32_t training, uint64_t seed, void* stream);
 
 /* GATConv(heads=1) message passing over one MFG hop (driver/models.py:195-231):
  *   e_ij = leaky_relu(a_src[j] + a_dst[i], negative_slope) over row i without its diagonal entry plus

@@ -117,6 +117,8 @@ SIGNATURES = {
     "spp_relu_dropout_backward": (C.c_int, [p, p, i64, C.c_float, p, p]),
     "spp_sage_operand_forward_act": (C.c_int, [p, p, i64, p, i64, p, i64, C.c_float, i32, C.c_uint64, p]),
     "spp_relu_dropout_backward_pre": (C.c_int, [p, p, i64, C.c_float, i32, C.c_uint64, p, p]),
+    "spp_sage_operand_backward_gather_act": (C.c_int, [p, p, i64, i64, i64, p, i64, i64, p, p, i64, p, C.c_float, i32,
+                                                       C.c_uint64, p]),
     "spp_gat_forward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p]),
     "spp_gat_logits": (C.c_int, [p, i32, i64, i64, i64, i64, p, p, p, p, p]),
     "spp_gat_logits_backward": (C.c_int, [p, i32, i64, i64, i64, i64, p, p, p, p, p]),

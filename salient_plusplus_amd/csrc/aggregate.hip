@@ -225,11 +225,16 @@ __global__ __launch_bounds__(kAggNT) void k_tr_fill(const int64_t* __restrict__ 
 }
 
 // grad_x[s,:] = (s < T ? grad_out[s, F:2F] : 0) + sum over the targets t of s: grad_out[t, :F] / deg(t)
+// kAct: grad_x is the gradient w.r.t. an ACTIVATED input whose pre-activation is z (dense [S, F]): the
+// ReLU + dropout backward (k_relu_dropout_bwd_pre) is applied to the row before it is stored, instead of a
+// separate read-modify-write pass over grad_x.
+template <bool kAct>
 __global__ __launch_bounds__(kAggNT) void k_operand_bwd_gather(const int32_t* __restrict__ start,
                                                                const int32_t* __restrict__ tcol,
                                                                const float* __restrict__ inv, int64_t T, int64_t S,
                                                                const float* __restrict__ g, int64_t go_stride, int64_t F,
-                                                               int lpr_log2, float* __restrict__ grad_x) {
+                                                               int lpr_log2, float* __restrict__ grad_x,
+                                                               const float* __restrict__ z, ActArgs act) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t srow = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
@@ -252,6 +257,13 @@ __global__ __launch_bounds__(kAggNT) void k_operand_bwd_gather(const int32_t* __
       const float w0 = inv[t0];
       const float4 v0 = *reinterpret_cast<const float4*>(g + (int64_t)t0 * go_stride + c);
       acc.x += v0.x * w0; acc.y += v0.y * w0; acc.z += v0.z * w0; acc.w += v0.w * w0;
+    }
+    if constexpr (kAct) {
+      const float4 zv = *reinterpret_cast<const float4*>(z + srow * F + c);
+      const f4 m = relu_dropout4(f4{zv.x, zv.y, zv.z, zv.w}, (srow * F + c) >> 2, act);  // > 0: z > 0 and kept
+      const float sc = act.training ? act.scale : 1.f;
+      acc = make_float4(m.x > 0.f ? acc.x * sc : 0.f, m.y > 0.f ? acc.y * sc : 0.f, m.z > 0.f ? acc.z * sc : 0.f,
+                        m.w > 0.f ? acc.w * sc : 0.f);
     }
     *reinterpret_cast<float4*>(grad_x + srow * F + c) = acc;
   }
@@ -405,11 +417,11 @@ extern "C" int64_t spp_sage_operand_backward_workspace_bytes(int64_t num_targets
   return up(4 * (num_sources + 1)) * 2 + up(4 * num_edges) + up(4 * num_targets) + up((int64_t)scan_tmp) + 64;
 }
 
-extern "C" spp_status spp_sage_operand_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev,
-                                                       int64_t num_targets, int64_t num_sources, int64_t num_edges,
-                                                       const float* grad_out_dev, int64_t grad_out_stride_elems,
-                                                       int64_t F, float* grad_x_dev, void* workspace_dev,
-                                                       int64_t workspace_bytes, void* stream) {
+static spp_status operand_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                          int64_t num_sources, int64_t num_edges, const float* grad_out_dev,
+                                          int64_t grad_out_stride_elems, int64_t F, float* grad_x_dev,
+                                          void* workspace_dev, int64_t workspace_bytes, const float* z_pre_dev,
+                                          ActArgs act, void* stream) {
   SPP_REQUIRE(num_targets >= 0 && num_sources >= num_targets && F >= 0 && num_edges >= 0,
               "spp_sage_operand_backward_gather: bad sizes");
   if (num_sources == 0 || F == 0) return SPP_OK;
@@ -444,10 +456,39 @@ extern "C" spp_status spp_sage_operand_backward_gather(const int64_t* rowptr_dev
     hipLaunchKernelGGL(k_tr_fill, dim3(gt), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, start, cnt, tcol);
   const int lpr_log2 = lanes_log2(F / 4);
   const unsigned grid = (unsigned)ceil_div(num_sources << lpr_log2, kAggNT);
-  hipLaunchKernelGGL(k_operand_bwd_gather, dim3(grid), dim3(kAggNT), 0, st, start, tcol, inv, num_targets, num_sources,
-                     grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev);
+  if (z_pre_dev)
+    hipLaunchKernelGGL(k_operand_bwd_gather<true>, dim3(grid), dim3(kAggNT), 0, st, start, tcol, inv, num_targets,
+                       num_sources, grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev, z_pre_dev, act);
+  else
+    hipLaunchKernelGGL(k_operand_bwd_gather<false>, dim3(grid), dim3(kAggNT), 0, st, start, tcol, inv, num_targets,
+                       num_sources, grad_out_dev, grad_out_stride_elems, F, lpr_log2, grad_x_dev, nullptr, ActArgs{});
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
+}
+
+extern "C" spp_status spp_sage_operand_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev,
+                                                       int64_t num_targets, int64_t num_sources, int64_t num_edges,
+                                                       const float* grad_out_dev, int64_t grad_out_stride_elems,
+                                                       int64_t F, float* grad_x_dev, void* workspace_dev,
+                                                       int64_t workspace_bytes, void* stream) {
+  return operand_backward_gather(rowptr_dev, col_dev, num_targets, num_sources, num_edges, grad_out_dev,
+                                 grad_out_stride_elems, F, grad_x_dev, workspace_dev, workspace_bytes, nullptr, ActArgs{},
+                                 stream);
+}
+
+// the same, followed in the same pass by the ReLU + dropout backward of spp_relu_dropout_backward_pre: grad_x
+// becomes the gradient w.r.t. the PRE-activation z_pre_dev (dense fp32 [S, F]) of the rows the forward activated on load
+extern "C" spp_status spp_sage_operand_backward_gather_act(const int64_t* rowptr_dev, const int64_t* col_dev,
+                                                           int64_t num_targets, int64_t num_sources, int64_t num_edges,
+                                                           const float* grad_out_dev, int64_t grad_out_stride_elems,
+                                                           int64_t F, float* grad_x_dev, void* workspace_dev,
+                                                           int64_t workspace_bytes, const float* z_pre_dev, float p,
+                                                           int32_t training, uint64_t seed, void* stream) {
+  SPP_REQUIRE(z_pre_dev && reinterpret_cast<uintptr_t>(z_pre_dev) % 16 == 0 && p >= 0.f && p < 1.f,
+              "spp_sage_operand_backward_gather_act: NULL / unaligned pre-activation or bad p");
+  return operand_backward_gather(rowptr_dev, col_dev, num_targets, num_sources, num_edges, grad_out_dev,
+                                 grad_out_stride_elems, F, grad_x_dev, workspace_dev, workspace_bytes, z_pre_dev,
+                                 act_args(p, training, seed), stream);
 }
 
 extern "C" spp_status spp_relu_dropout_forward(const float* x_dev, int64_t n, float p, int32_t training, uint64_t seed,

@@ -297,16 +297,18 @@ class _SageStack(torch.autograd.Function):
             gA = gZ @ W                                                         # [T, 2K]
             gH = torch.empty((S, K), dtype=torch.float32, device=gA.device)
             E = col.numel()
+            p_, training_, seeds = ctx.act
             if E * K >= (1 << 22):
+                # gather over the transposed hop, with the ReLU + dropout backward applied before the row is stored
                 nbytes = int(L.spp_sage_operand_backward_workspace_bytes(T, S, E))
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=gA.device)
-                nat.check(L.spp_sage_operand_backward_gather(_p(rowptr), _p(col), T, S, E, _p(gA), 2 * K, K, _p(gH),
-                                                             _p(ws), nbytes, st))
+                nat.check(L.spp_sage_operand_backward_gather_act(_p(rowptr), _p(col), T, S, E, _p(gA), 2 * K, K, _p(gH),
+                                                                 _p(ws), nbytes, _p(acts[i - 1]), p_, training_,
+                                                                 seeds[i - 1], st))
             else:
                 nat.check(L.spp_sage_operand_backward(_p(rowptr), _p(col), T, S, _p(gA), 2 * K, K, _p(gH), st))
-            p_, training_, seeds = ctx.act
-            nat.check(L.spp_relu_dropout_backward_pre(_p(gH), _p(acts[i - 1]), gH.numel(), p_, training_, seeds[i - 1],
-                                                      _p(gH), st))
+                nat.check(L.spp_relu_dropout_backward_pre(_p(gH), _p(acts[i - 1]), gH.numel(), p_, training_,
+                                                          seeds[i - 1], _p(gH), st))
             gZ = gH
         ctx.saved = None
         return (None, None, None, None, *grads)

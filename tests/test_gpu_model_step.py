@@ -294,6 +294,21 @@ def test_activation_on_load_equals_the_separate_pass(training):
     nat.check(L.spp_relu_dropout_backward_pre(P(g), P(z), g.numel(), p_drop, training, seed, P(gx_pre), st))
     torch.cuda.synchronize()
     assert torch.equal(gx_pre, gx_ref)
+    # ... and the gather backward with that step in its epilogue equals gather + separate step
+    E = int(col.numel())
+    gA = torch.randn((T, 2 * F), device="cuda")
+    nbytes = int(L.spp_sage_operand_backward_workspace_bytes(T, S, E))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    g_plain, g_act = torch.empty((S, F), device="cuda"), torch.empty((S, F), device="cuda")
+    nat.check(L.spp_sage_operand_backward_gather(P(rowptr), P(col), T, S, E, P(gA), 2 * F, F, P(g_plain), P(ws), nbytes, st))
+    nat.check(L.spp_relu_dropout_backward_pre(P(g_plain), P(z), g_plain.numel(), p_drop, training, seed, P(g_plain), st))
+    nat.check(L.spp_sage_operand_backward_gather_act(P(rowptr), P(col), T, S, E, P(gA), 2 * F, F, P(g_act), P(ws), nbytes,
+                                                     P(z), p_drop, training, seed, st))
+    torch.cuda.synchronize()
+    # (the transposed hop is filled with atomics: the order of a source's targets, hence the last bits of the sums,
+    # differ from call to call -- the mask must agree exactly, the values to rounding)
+    assert torch.equal(g_act == 0, g_plain == 0)
+    torch.testing.assert_close(g_act, g_plain, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("K,N,dtype", [(128, 256, torch.float16), (256, 64, torch.float32), (100, 47, torch.float32)])
