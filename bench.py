@@ -179,13 +179,20 @@ class EpochFeeder:
         return self._xb[0] + cur[0], self._xb[1] + cur[1]
 
     def _new_epoch(self):
+        t0 = time.perf_counter()
         if self.devit is not None:
             self._xb = self.exchange_bytes()
             # finish the old epoch's Session first: its sampler (workspace, exchange buffers) goes back to
             # the pool and the new Session reuses it instead of building a second one
             self.devit = None
+        t1 = time.perf_counter()
         self.shuffler.set_epoch(self.epoch)
-        self.devit = self.make_iter(self.get_idx())
+        idx = self.get_idx()
+        t2 = time.perf_counter()
+        self.devit = self.make_iter(idx)
+        if os.environ.get("SPP_BENCH_STEP_TIMES") == "1":
+            print(f"[bench] epoch {self.epoch} set-up: old iterator released {1e3 * (t1 - t0):.2f} ms, seed order "
+                  f"{1e3 * (t2 - t1):.2f} ms, new iterator {1e3 * (time.perf_counter() - t2):.2f} ms", file=sys.stderr, flush=True)
         self.epoch += 1
 
     def quiesce(self):
@@ -200,7 +207,11 @@ class EpochFeeder:
             try:
                 return next(self.devit)[0]
             except StopIteration:
-                self._new_epoch()
+                pass
+            # outside the except block: while the exception is being handled its traceback keeps the old
+            # iterator (and its Session) alive, the pooled sampler is still taken and the new epoch would build
+            # a second one (9 ms and 2.4 GB)
+            self._new_epoch()
 
 
 def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
@@ -521,7 +532,7 @@ def main():
     for _w in range(R):
         edges = nodes = 0
         t0 = time.perf_counter()
-        step_t = [] if os.environ.get("SPP_BENCH_STEP_TIMES") == "1" and _w in (2, 3) else None
+        step_t = [] if os.environ.get("SPP_BENCH_STEP_TIMES") == "1" else None
         for _ in range(a.steps):
             ts = time.perf_counter()
             b = feeder.next()
@@ -532,8 +543,10 @@ def main():
         ts = time.perf_counter()
         torch.cuda.synchronize()
         if step_t is not None:                    # diagnostic: host time of every step of a window, and of its closing synchronize
-            print(f"[bench] window {_w}: host us per step " + " ".join(f"{v:.0f}" for v in step_t) +
-                  f" | synchronize {(time.perf_counter() - ts) * 1e6:.0f}", file=sys.stderr, flush=True)
+            shown = step_t if len(step_t) <= 24 else sorted(step_t)[-8:]
+            print(f"[bench] window {_w}: host us per step ({'all' if len(step_t) <= 24 else 'the 8 longest'}) " +
+                  " ".join(f"{v:.0f}" for v in shown) + f" | synchronize {(time.perf_counter() - ts) * 1e6:.0f}",
+                  file=sys.stderr, flush=True)
         if distributed:
             feeder.quiesce()
             dist.barrier()

@@ -443,6 +443,7 @@ class Session:
         self.config = config
         self._L = L
         self._h = None
+        self._final = {"total": 0, "consumed": 0, "group": 0, "blocked_us": 0, "blocked_n": 0, "xbytes": (0, 0)}
         self._dev = _device()
         self._sizes = _as_i64_list(config.sizes)
         self._rowptr = _resident.get(config.rowptr, torch.int64)
@@ -593,8 +594,27 @@ class Session:
         return (pc, key, cmap)
 
     # ---- lifetime ----
+    def _finish(self):
+        """End of data: nothing more will be produced, so the native session ends and the (pooled) sampler goes
+        back to the pool NOW -- not when the last Python reference to this object dies.  A training loop
+        typically builds the next epoch's iterator while the old one is still bound (`it = iter(sampler)`, a
+        StopIteration being handled, ...); the next Session would then find the pool empty and build a second
+        sampler (9 ms, 2.4 GB of slots and a second 5 GB stream arena at papers scale)."""
+        self.close()
+
     def close(self):
         if getattr(self, "_h", None) is not None:
+            try:                # the counters outlive the native session (get_stats() after the last batch)
+                self._final = {
+                    "total": int(self._L.spp_session_num_total_batches(self._h)),
+                    "consumed": int(self._L.spp_session_num_consumed_batches(self._h)),
+                    "group": int(self._L.spp_session_group_size(self._h)),
+                    "blocked_us": int(self._L.spp_session_blocked_us(self._h)),
+                    "blocked_n": int(self._L.spp_session_blocked_occasions(self._h)),
+                    "xbytes": self.exchange_bytes(),
+                }
+            except Exception:
+                pass
             self._L.spp_session_destroy(self._h)
             self._h = None
         if getattr(self, "_pool_entry", None) is not None:
@@ -612,7 +632,7 @@ class Session:
         """The sampler's persistent delivery stream as a torch stream: exporting batches on it keeps
         the per-batch delivery kernel on a hardware queue that no sampling stream shares."""
         if self._consumer_stream is None:
-            ptr = self._L.spp_sampler_deliver_stream(self._pool_entry[0])
+            ptr = self._L.spp_sampler_deliver_stream(self._pool_entry[0]) if self._pool_entry is not None else None
             self._consumer_stream = torch.cuda.ExternalStream(ptr, device=self._dev) if ptr else \
                 torch.cuda.Stream(self._dev)
         return self._consumer_stream
@@ -620,16 +640,16 @@ class Session:
     # ---- properties of fast_sampler.cpp:1325-1338 ----
     @property
     def num_total_batches(self) -> int:
-        return int(self._L.spp_session_num_total_batches(self._h))
+        return int(self._L.spp_session_num_total_batches(self._h)) if self._h is not None else self._final["total"]
 
     @property
     def num_consumed_batches(self) -> int:
-        return int(self._L.spp_session_num_consumed_batches(self._h))
+        return int(self._L.spp_session_num_consumed_batches(self._h)) if self._h is not None else self._final["consumed"]
 
     @property
     def group_size(self) -> int:
         """batches sampled (and, in distributed mode, exchanged) together"""
-        return int(self._L.spp_session_group_size(self._h))
+        return int(self._L.spp_session_group_size(self._h)) if self._h is not None else self._final["group"]
 
     @property
     def approx_num_complete_batches(self) -> int:
@@ -637,17 +657,22 @@ class Session:
 
     @property
     def total_blocked_dur(self) -> datetime.timedelta:
-        return datetime.timedelta(microseconds=int(self._L.spp_session_blocked_us(self._h)))
+        us = int(self._L.spp_session_blocked_us(self._h)) if self._h is not None else self._final["blocked_us"]
+        return datetime.timedelta(microseconds=us)
 
     @property
     def total_blocked_occasions(self) -> int:
-        return int(self._L.spp_session_blocked_occasions(self._h))
+        return int(self._L.spp_session_blocked_occasions(self._h)) if self._h is not None else self._final["blocked_n"]
 
     # ---- batch production ----
     def _next_desc(self, block=True):
+        if self._h is None:     # ended (and released) earlier
+            return False
         fn = self._L.spp_session_next if block else self._L.spp_session_try_next
         rc = fn(self._h, C.byref(self._desc))
         nat.check(rc)
+        if rc == 0:             # end of data: release the sampler right away (see _finish)
+            self._finish()
         return rc == 1          # 0: end of data, 2: not ready yet (non-blocking form only)
 
     def _alloc_mfg(self, counts, want_n_id=True, num_parts=0):
@@ -831,6 +856,8 @@ class Session:
 
     def exchange_bytes(self):
         """(sent, received) bytes of the native exchange so far."""
+        if self._h is None:
+            return self._final["xbytes"]
         a, b = C.c_int64(0), C.c_int64(0)
         nat.check(self._L.spp_session_exchange_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)

@@ -19,13 +19,34 @@ class Shuffler:
         # The permutation always comes from the CPU generator (where the reference keeps its ids), so
         # a given (seed, epoch) orders the ids identically whether they live on the host or in HBM.
         self.generator = torch.Generator(device="cpu")
+        self._ahead = None     # (epoch, thread, [result]): the NEXT epoch's permutation, computed in the background
 
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
+    def _compute(self, epoch: int, generator: torch.Generator) -> torch.Tensor:
+        generator.manual_seed(self.initial_seed + epoch)
+        return torch.randperm(self.initial_idx.numel(), generator=generator)
+
     def _permutation(self) -> torch.Tensor:
-        self.generator.manual_seed(self.initial_seed + self.epoch)
-        return torch.randperm(self.initial_idx.numel(), generator=self.generator)
+        """The permutation of (initial_seed, epoch) -- a pure function of the two.  Epochs come one after the
+        other, so the next one's is computed on a background thread while this epoch runs (5 ms for 1.2 M ids
+        that would otherwise sit between two epochs with the GPU idle); an unexpected epoch number just
+        computes its own."""
+        import threading
+        e = self.epoch
+        order = None
+        if self._ahead is not None and self._ahead[0] == e:
+            self._ahead[1].join()
+            order = self._ahead[2][0] if self._ahead[2] else None
+        self._ahead = None
+        if order is None:
+            order = self._compute(e, self.generator)
+        box = []
+        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))), daemon=True)
+        th.start()
+        self._ahead = (e + 1, th, box)
+        return order
 
     def get_idx(self):
         order = self._permutation().to(self.initial_idx.device)

@@ -206,6 +206,25 @@ def test_distributed_proto_batch_vs_oracle(fs, graph_a, P, rank, use_cache, size
     assert nb == 3
 
 
+def test_sampler_goes_back_to_the_pool_at_end_of_data(fs, graph_a):
+    """An exhausted iterator that is still referenced (the usual `it = iter(sampler)` of the next epoch, a
+    StopIteration being handled) must not keep the pooled sampler: the next epoch's Session reuses it instead
+    of building a second workspace."""
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    cfg = make_cfg(fs, graph_a, [15, 10, 5], 64, graph_a["x"], graph_a["y"], graph_a["idx"])
+    smp = FastSampler(2, 4, cfg)
+    it1 = iter(smp)
+    h1 = it1.session._pool_entry[0].value
+    n1 = sum(1 for _ in it1)
+    assert n1 > 0 and it1.session._pool_entry is None            # released at end of data, object still alive
+    stats = it1.get_stats()
+    assert stats.total_blocked_occasions >= 0                     # counters survive the native session
+    it2 = iter(smp)                                               # it1 still bound
+    assert it2.session._pool_entry[0].value == h1
+    assert sum(1 for _ in it2) == n1
+    assert it1.session.num_consumed_batches == n1 and next(it1, None) is None
+
+
 def test_cache_map_rebuilt_in_place_between_sessions(fs, graph_a):
     """The bucketing kernels test cache membership through a bitmap derived from the cache map; the pooled
     sampler keeps it across Sessions, so it is rebuilt at every Session start.  Two Sessions over the SAME map
