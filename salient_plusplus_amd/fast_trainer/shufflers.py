@@ -43,7 +43,7 @@ class Shuffler:
         if order is None:
             order = self._compute(e, self.generator)
         box = []
-        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))), daemon=True)
+        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))))  # not a daemon: a few ms, joined at interpreter exit
         th.start()
         self._ahead = (e + 1, th, box)
         return order
