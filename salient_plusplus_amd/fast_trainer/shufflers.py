@@ -43,7 +43,8 @@ class Shuffler:
         if order is None:
             order = self._compute(e, self.generator)
         box = []
-        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))))  # not a daemon: a few ms, joined at interpreter exit
+        # (not a daemon thread: it runs for a few ms and is joined at interpreter exit)
+        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))))
         th.start()
         self._ahead = (e + 1, th, box)
         return order
