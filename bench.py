@@ -8,7 +8,8 @@ BASELINE.json's multi-GPU configurations name (synthetic.py: LOCALITY; `--worklo
 is the same graph without it -- identical single-GPU numbers, 7/8 of all neighbours remote on 8 GPUs).
 `--workload S-products` runs BASELINE.json's configs[1] instead.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: this script starts
+                                                           its N rank processes itself, as children)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one batch through the hot path.  N == 1: single-GPU iterator (FastSampler +
@@ -120,16 +121,24 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=24, warm=4, hip=True, arch="sage"):
-    """ms/step of fwd+bwd+Adam with the data path feeding it, and with one resident batch re-used.
-    hip=True: salient_plusplus_amd.models.SAGE (HIP mean aggregation); False: the plain-torch
-    formulation above."""
+def model_step_timing(feeder, F, n_classes, steps=24, warm=8, windows=6, hip=True, arch="sage", ddp=False):
+    """ms/step of fwd+bwd+Adam with one resident batch re-used, and with the data path feeding it (the
+    training step of fast_trainer/train.py:15-71).  Measured like the data path: `windows` back-to-back
+    windows of `steps` steps, the MEDIAN window reported and all of them kept -- a fresh process pays a few
+    multi-millisecond allocator growths while the model's batch-size-dependent temporaries meet their
+    largest shapes, and one 24-step sample after 4 warm-up steps (round 2) carried them into the figure.
+    hip=True: salient_plusplus_amd.models (HIP message passing); False: the plain-torch formulation
+    above.  ddp=True: the model is wrapped in DistributedDataParallel on the caller's NCCL process group
+    (driver/drivers/ddp.py:349-350), so every backward issues gradient all-reduces between the exchanges.
+    Returns (model_only_ms, with_data_ms, detail)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if hip:
         from salient_plusplus_amd.models import GAT, SAGE
         model = (GAT if arch == "gat" else SAGE)(F, 256, n_classes, 3).to(dev)
     else:
         model = TorchSAGE(F, 256, n_classes).to(dev)
+    if ddp:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)    # one multi-tensor launch per step
 
     def step(b):
@@ -138,24 +147,35 @@ def model_step_timing(feeder, F, n_classes, steps=24, warm=4, hip=True, arch="sa
         loss.backward()
         opt.step()
 
+    show = os.environ.get("SPP_BENCH_STEP_TIMES") == "1"
+
+    def run_windows(get, tag):
+        for _ in range(warm):
+            step(get())
+        torch.cuda.synchronize()
+        out = []
+        for w in range(windows):
+            host = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ts = time.perf_counter()
+                step(get())
+                host.append((time.perf_counter() - ts) * 1e6)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps * 1e3)
+            if show:
+                print(f"[bench] model step ({tag}) window {w}: {out[-1]:.3f} ms/step; host us per step " +
+                      " ".join(f"{v:.0f}" for v in host), file=sys.stderr, flush=True)
+        srt = sorted(out)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        return med, out
+
     fixed = feeder.next()
-    for _ in range(warm):
-        step(fixed)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(fixed)
-    torch.cuda.synchronize()
-    model_only = (time.perf_counter() - t0) / steps
-    for _ in range(warm):
-        step(feeder.next())
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step(feeder.next())
-    torch.cuda.synchronize()
-    with_data = (time.perf_counter() - t0) / steps
-    return model_only * 1e3, with_data * 1e3
+    m_only, w_only = run_windows(lambda: fixed, "resident batch")
+    m_data, w_data = run_windows(feeder.next, "with data path")
+    detail = {"windows": windows, "steps_each": steps, "warmup_steps": warm, "reported": "median window",
+              "model_only_ms_all": [round(v, 4) for v in w_only], "with_data_path_ms_all": [round(v, 4) for v in w_data]}
+    return m_only, m_data, detail
 
 
 def count_edges(batch) -> int:
@@ -274,30 +294,50 @@ def cpu_baseline(wl_host, sizes, batch_size, seconds, threads):
             "batches_per_s": nb / dt}
 
 
-class device_turn:
-    """Rehearsal mode only (SPP_BENCH_REHEARSAL=1: several ranks share ONE GPU, a development aid).
-    torch's device-wide primitives -- the rocPRIM radix sort / scan behind sort, unique, topk, randperm,
-    cumsum -- stall when several PROCESSES run them concurrently on one device: plain torch.sort hangs
-    with four processes (tools/diag_multiproc_primitives.py, profiles/r02_diag_multiproc_primitives.txt);
-    that, not a kernel of this repository, is what round 1 saw as "all ranks inside torch.unique".
-    The set-up phases that use such primitives (graph construction, cache ranking) therefore take
-    turns under a file lock.  One process per GPU -- every real run -- needs and does nothing here."""
-
-    def __enter__(self):
-        self.f = None
-        if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
-            import fcntl
-            self.f = open("/tmp/spp_bench_rehearsal.lock", "w")
-            fcntl.flock(self.f, fcntl.LOCK_EX)
-        return self
-
-    def __exit__(self, *exc):
-        if self.f is not None:
-            import fcntl
-            torch.cuda.synchronize()
-            fcntl.flock(self.f, fcntl.LOCK_UN)
-            self.f.close()
-        return False
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N rank processes as
+    CHILDREN of this one (which has not touched the GPU: torch.cuda.device_count() does not initialise it),
+    one per GPU, relay rank 0's JSON line on stdout and return the children's status -- the counterpart of
+    the reference's mp.spawn(ddp_main, nprocs=num_devices_per_node) (driver/main.py:365-366)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        print(f"[bench] --gpus {a.gpus} needs {a.gpus} GPUs, this node shows {n_dev}: refusing to run fewer ranks "
+              f"than asked for", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:                       # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # only rank 0 prints the line; whatever else a rank writes to stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench] rank {procs.index(p)} exited with status {code}: stopping the other ranks",
+                          file=sys.stderr, flush=True)
+                    for q in pending:                 # exactly the processes started above
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def _trace(msg):
@@ -311,13 +351,16 @@ def main():
     if os.environ.get("SPP_BENCH_TRACE") == "1":
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("SPP_BENCH_TRACE_AFTER", "60")), exit=False)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))               # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: the line would "
+                         f"not describe the run that was asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X data path has no CPU fallback")
-    if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
-        local_rank = 0                      # all ranks share the one GPU (development aid, see below)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or a.force_distributed
@@ -326,26 +369,7 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if os.environ.get("SPP_BENCH_REHEARSAL") == "1":
-            # Development aid: several ranks on ONE GPU (RCCL refuses that) -- gloo with host-staged
-            # all_to_all_single, hence the torch.distributed transport; exercises this script's N>1
-            # code path, not a performance configuration.
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            real_a2a = dist.all_to_all_single
-
-            def staged(output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
-                o = torch.empty(output.shape, dtype=output.dtype)
-                real_a2a(o, input.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes,
-                         group=group)
-                output.copy_(o)
-
-                class _Done:
-                    def wait(self):
-                        return True
-                return _Done() if async_op else None
-            dist.all_to_all_single = staged
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from salient_plusplus_amd import _native as nat
     from salient_plusplus_amd import fast_sampler as fs
@@ -358,8 +382,7 @@ def main():
     nat.require_device()
     _trace("process group up, building the workload")
     t_build = time.perf_counter()
-    with device_turn():
-        wl = make_workload(a.workload, seed=1234, device=dev)
+    wl = make_workload(a.workload, seed=1234, device=dev)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     N, F = wl.num_nodes, wl.x.size(1)
@@ -400,19 +423,17 @@ def main():
             if a.seed_scheme == "federated" else wl.train_idx
         n_cache = int(a.cache_frac * N / world) if world > 1 else 0
         if n_cache > 0 and a.cache_strategy == "degree-desc":
-            with device_turn():
-                deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
-                deg_remote[lo:hi] = -1
-                wanted = torch.topk(deg_remote, n_cache).indices.sort().values
+            deg_remote = (wl.rowptr[1:] - wl.rowptr[:-1]).clone()
+            deg_remote[lo:hi] = -1
+            wanted = torch.topk(deg_remote, n_cache).indices.sort().values
             cv, cf = fetch_cache_rows(pb, wanted, x_local)
             cache = fs.Cache(rank, world, cv, cf)
         elif n_cache > 0:
-            # create_vip_cache (ddp.py:417-570) in its two halves: the ranking (device-wide sorts: one rank
-            # at a time when the ranks share a GPU) and the collective fetch of the rows from their owners
+            # create_vip_cache (ddp.py:417-570) in its two halves: the ranking and the collective fetch of the
+            # rows from their owners
             from salient_plusplus_amd.fast_trainer.vip_cache import rank_remote_vertices
-            with device_turn():
-                wanted = rank_remote_vertices(a.cache_strategy, pb, N, int(N / world * a.cache_frac), rowptr=wl.rowptr,
-                                              col=wl.col, train_idx=vip_seeds, fanouts=sizes, batch_size=bs)
+            wanted = rank_remote_vertices(a.cache_strategy, pb, N, int(N / world * a.cache_frac), rowptr=wl.rowptr,
+                                          col=wl.col, train_idx=vip_seeds, fanouts=sizes, batch_size=bs)
             cv, cf = fetch_cache_rows(pb, wanted, x_local)
             cache = fs.Cache(rank, world, cv, cf)
             n_cache = int(cache.cached_vertices.numel())
@@ -471,6 +492,9 @@ def main():
         exchange_verified = None
         verified_per_rank = None
         rccl_world = int(L.spp_comm_world(fs.native_comm().handle)) if native else 0
+        if world > 1 and native and rccl_world != world:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: the native exchange communicator spans {rccl_world} ranks, "
+                             f"the process group {world}")
         if native and not a.no_verify:
             import dataclasses
             n_check = min(8, max(1, n_local // bs))
@@ -575,6 +599,45 @@ def main():
     window_ms = [w[0] / a.steps * 1e3 for w in win]
     timed_total_s = sum(w[0] for w in win)
 
+    # ---- the metric's second half: epoch time with the model step consuming the batches -------------
+    # N == 1: models.py SAGE / GAT on the single-GPU iterator.  N > 1: the same model under
+    # DistributedDataParallel on torch's NCCL process group (driver/drivers/ddp.py:349-350,
+    # fast_trainer/train.py:15-71): gradient all-reduces of one communicator interleave with the feature
+    # exchanges of another, so the Sessions of this leg issue their exchanges from the consumer thread, at the
+    # same program point on every rank (SPP_EXCHANGE_ISSUE=consumer).  All ranks take part.
+    model_out = None
+    if not a.no_model_step:
+        try:
+            if distributed:
+                feeder.quiesce()
+                feeder.devit = None                  # the thread-issued Session ends here
+                gc.collect()
+                os.environ["SPP_EXCHANGE_ISSUE"] = "consumer"
+                dist.barrier()
+            m_only, m_data, m_detail = model_step_timing(feeder, F, 47, hip=True, arch=a.model, ddp=distributed)
+            if distributed:
+                feeder.quiesce()
+                t = torch.tensor([m_only, m_data], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the slowest rank's step
+                m_only, m_data = (float(v) for v in t.cpu().tolist())
+            nb_epoch = (wl.train_idx.numel() // bs) if not distributed else max(1, n_local // bs)
+            model_out = {"epoch_time_s_with_model_step": nb_epoch * m_data / 1e3,
+                         "model_step": {"model": f"{a.model.upper()} 3x256 (models.py: HIP message passing + library GEMMs, "
+                                                 f"fp32, fused ReLU+dropout, Adam(fused=True))" +
+                                                 (f", DistributedDataParallel over {world} ranks, exchanges issued by the consumer"
+                                                  if distributed else ""),
+                                        "batches_per_epoch_and_rank": nb_epoch,
+                                        "ms_per_step_model_only_resident_batch": m_only,
+                                        "ms_per_step_with_data_path": m_data, "timing": m_detail}}
+            if not distributed:
+                t_only, t_data, _ = model_step_timing(feeder, F, 47, hip=False, windows=2, warm=4)
+                model_out["model_step"]["plain_torch_formulation"] = {
+                    "ms_per_step_model_only_resident_batch": t_only, "ms_per_step_with_data_path": t_data}
+        except Exception as e:  # noqa: BLE001
+            if distributed:
+                raise                                 # a rank that fell out of a collective sequence: fail loudly
+            model_out = {"model_step": {"error": repr(e)}}
+
     from salient_plusplus_amd.synthetic import LOCALITY
     locality_note = ""
     if a.workload in LOCALITY:
@@ -605,7 +668,8 @@ def main():
             pmc = json.load(open(pmc_path))
             if pmc["shape"]["row_bytes"] == row_bytes:
                 roof["traffic"] = pmc["traffic_bytes_per_row"] * roof["rows_per_launch"]
-                roof["traffic_source"] = f"profiles/{pmc_name} (bytes/row x rows/launch)"
+                roof["traffic_source"] = (f"profiles/{pmc_name}: PMC bytes/row of this kernel from an earlier rocprofv3 "
+                                          f"--pmc pass (NOT measured in this run) x this run's rows/launch")
                 roof["algorithmic_bytes_per_launch"] = alg_bytes_per_row * roof["rows_per_launch"]
                 break
         out = {
@@ -620,6 +684,7 @@ def main():
                         "ms_per_step_min": min(window_ms), "ms_per_step_median": dt / a.steps * 1e3,
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
                         "ms_per_step_all": [round(v, 5) for v in window_ms]},
+            "timed_region_s": timed_total_s,          # all R windows (also under "windows")
             "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
@@ -641,24 +706,14 @@ def main():
                                "rank0_received_MB_per_batch": recv / n_timed / 1e6,
                                "rank0_GBps_out": sent / timed_total_s / 1e9, "rank0_GBps_in": recv / timed_total_s / 1e9,
                                "xgmi_peak_GBps_per_gpu": 7 * 153.0}
-        if not a.no_model_step and not distributed:
-            try:
-                m_only, m_data = model_step_timing(feeder, F, 47, hip=True, arch=a.model)
-                t_only, t_data = model_step_timing(feeder, F, 47, hip=False)
-                nb_epoch = wl.train_idx.numel() // bs
-                out["epoch_time_s_with_model_step"] = nb_epoch * m_data / 1e3
-                out["model_step"] = {"model": f"{a.model.upper()} 3x256 (models.py: HIP message passing + library GEMMs, "
-                                              f"fp32, fused ReLU+dropout, Adam(fused=True))",
-                                     "ms_per_step_model_only_resident_batch": m_only,
-                                     "ms_per_step_with_data_path": m_data,
-                                     "plain_torch_formulation": {"ms_per_step_model_only_resident_batch": t_only,
-                                                                 "ms_per_step_with_data_path": t_data}}
-            except Exception as e:  # noqa: BLE001
-                out["model_step"] = {"error": repr(e)}
+        if model_out is not None:
+            out.update(model_out)
         if not a.no_cpu_baseline and not distributed:
             threads = host_cpu_share()
             host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
             out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
+            out["cpu_baseline"]["cores_source"] = (f"min(sched_getaffinity = {len(os.sched_getaffinity(0))}, cgroup cpu.max quota) "
+                                                   f"= {threads}; os.cpu_count() shows {os.cpu_count()}")
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if distributed:

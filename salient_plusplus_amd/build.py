@@ -24,6 +24,12 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    # the flag set is part of what the objects were built from: an A/B script that compiled a variant with
+    # SPP_EXTRA_FLAGS must not leave it behind for the next bench / test / profile on the same box
+    stamp = os.path.join(OBJ, "flags.stamp")
+    flags_now = " ".join([HIPCC] + FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".cuh"))]
     headers += [os.path.join(ROOT, "include", "spp.h"), os.path.abspath(__file__)]
     jobs = []
@@ -43,6 +49,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-ldl"])
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return LIB
 
 

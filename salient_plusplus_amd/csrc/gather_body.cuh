@@ -74,26 +74,67 @@ __device__ __forceinline__ void move_rows_body(KeyFn key_of, PtrFn ptr_of, int64
   const int l = threadIdx.x & (lpr - 1);
   const int gpb = kGatherThreads >> lpr_log2;  // row groups per workgroup
   const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
-  for (int64_t base = vblock * rows_per_iter; base < n; base += nvblocks * rows_per_iter) {
-    // Branch-free loads: a row index past the end is clamped to the last row (loaded, never stored).  With
-    // `if (ok) v = load` the compiler put every load in its own exec-masked block behind an
-    // s_waitcnt vmcnt(0) -- ONE load in flight per wavefront whatever the unroll; now the kGatherUnroll
-    // key loads, then the kGatherUnroll row loads, are issued back to back.
-    decltype(key_of((int64_t)0)) key[kGatherUnroll];
+  // Software pipeline over the workgroup's grid-stride iterations: the keys of iteration k+1 are requested
+  // right after the row loads of iteration k, so that an iteration costs ONE dependent round trip (rows) instead
+  // of two (key, then row).  Loads return in order, so waiting for the rows leaves the younger key loads in flight.
+  // Branch-free loads throughout: a row index past the end is clamped to the last row (loaded, never stored).
+  // With `if (ok) v = load` the compiler put every load in its own exec-masked block behind an
+  // s_waitcnt vmcnt(0) -- ONE load in flight per wavefront whatever the unroll.
+  using K = decltype(key_of((int64_t)0));
+  const int64_t stride = nvblocks * rows_per_iter;
+  int64_t base = vblock * rows_per_iter;
+  if (base >= n) return;
+  // lpr is the power of two >= chunks: lanes past the row's last access load piece 0 (not predicated) and store nothing
+  const bool lane_on = l < chunks;
+  const int l0 = lane_on ? l : 0;
+  K key_next[kGatherUnroll];
+#pragma unroll
+  for (int u = 0; u < kGatherUnroll; ++u) {
+    const int64_t r = base + (int64_t)u * gpb + g;
+    key_next[u] = key_of(r < n ? r : n - 1);
+  }
+  // Two bodies, chosen by WORKGROUP-UNIFORM conditions (a scalar branch): the full one -- every row of the
+  // iteration exists and every lane of a group has a piece of the row -- stores unconditionally.  With a per-lane
+  // predicate on the store the compiler sinks the row's LOAD into the predicated block as well (its only use),
+  // behind an s_waitcnt vmcnt(0): that load then waits for everything in flight, the prefetched keys included.
+  const bool dense_lanes = chunks == lpr;
+  for (; base < n; base += stride) {
     const V* s[kGatherUnroll];
     V* d[kGatherUnroll];
-    bool ok[kGatherUnroll];
+    V v[kGatherUnroll];
+    const int64_t nbase = base + stride;
 #pragma unroll
     for (int u = 0; u < kGatherUnroll; ++u) {
       const int64_t r = base + (int64_t)u * gpb + g;
-      ok[u] = r < n;
-      key[u] = key_of(ok[u] ? r : n - 1);
       d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
+      s[u] = reinterpret_cast<const V*>(ptr_of(key_next[u]));
+    }
+    if (dense_lanes && base + rows_per_iter <= n) {
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][l]) : s[u][l];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) {  // next iteration's keys (clamped: past the end they are never used)
+        const int64_t r = nbase + (int64_t)u * gpb + g;
+        key_next[u] = key_of(r < n ? r : n - 1);
+      }
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) __builtin_nontemporal_store(v[u], &d[u][l]);
+      continue;
+    }
+    bool ok[kGatherUnroll];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) ok[u] = base + (int64_t)u * gpb + g < n;
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][l0]) : s[u][l0];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) {
+      const int64_t r = nbase + (int64_t)u * gpb + g;
+      key_next[u] = key_of(r < n ? r : n - 1);
     }
 #pragma unroll
-    for (int u = 0; u < kGatherUnroll; ++u) s[u] = reinterpret_cast<const V*>(ptr_of(key[u]));
-    for (int c = l; c < chunks; c += lpr) {
-      V v[kGatherUnroll];
+    for (int u = 0; u < kGatherUnroll; ++u)
+      if (ok[u] && lane_on) __builtin_nontemporal_store(v[u], &d[u][l]);
+    for (int c = l + lpr; c < chunks; c += lpr) {  // rows wider than one access per lane
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
 #pragma unroll

@@ -805,8 +805,12 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
     s->blocked_occasions++;
   }
   if (rc == SPP_OK && s->tr) {
-    const int32_t* aw = async_err_word(s->cfg.device);
-    const int32_t bits = aw ? __atomic_load_n(aw, __ATOMIC_ACQUIRE) : 0;
+    // reported once: the bits are cleared as they are read, so that a later Session on this device (another
+    // sampler, another communicator) does not fail on a stale error of this one
+    int32_t* aw = async_err_word(s->cfg.device);
+    int32_t bits = aw ? __atomic_load_n(aw, __ATOMIC_ACQUIRE) : 0;
+    if (bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE))
+      bits = __atomic_fetch_and(aw, ~(SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE), __ATOMIC_ACQ_REL);
     if (bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE)) {
       set_error("feature exchange: a row outside its table was requested (async error mask %d: 2 = a peer asked this "
                 "rank for a row it does not own, 4 = assembly source out of range) -- the ranks disagree on the "

@@ -94,11 +94,18 @@ def _bucket_splits(split_idx: Mapping[str, torch.Tensor], order: _VertexOrder):
 
 
 def _take_rows(t: torch.Tensor, rows: torch.Tensor, device) -> torch.Tensor:
-    """t[rows] on `device`; 2-D tables go through the HIP row gather (spp_gather_rows) when that is a GPU"""
+    """t[rows] on `device`; 2-D tables go through the HIP row gather (spp_gather_rows) when that is a GPU.
+    Offline path: synchronises and raises when a row index was outside the table (the kernel clamps, it
+    does not fault)."""
     device = torch.device(device)
     if device.type == "cuda" and t.dim() == 2 and t.stride(-1) == 1:
         from . import fast_sampler as fs
-        return fs.serial_index(t.to(device), rows.to(device))
+        out = fs.serial_index(t.to(device), rows.to(device))
+        torch.cuda.current_stream(device).synchronize()
+        bits = fs.async_errors(clear=True, device=device)
+        if bits & 1:
+            raise IndexError(f"row index outside the {t.size(0)}-row table (async error mask {bits})")
+        return out
     return t.to(device)[rows.to(device)]
 
 

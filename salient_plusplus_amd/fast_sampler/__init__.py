@@ -28,7 +28,7 @@ from .. import _native as nat
 
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
            "multilayer_sample", "full_sample", "to_row_major", "serial_index", "NativeComm", "native_comm",
-           "set_native_comm"]
+           "set_native_comm", "async_errors"]
 
 # four slot-sets of 8 batches (~75 MB of workspace each at fanout [15,10,5], batch 1024): with two, a
 # set's next sampling chain could only start once its previous group was consumed and the consumer
@@ -1020,8 +1020,19 @@ def to_row_major(t: torch.Tensor) -> torch.Tensor:
     return out if t.is_cuda else out.cpu()
 
 
+def async_errors(clear: bool = True, device=None) -> int:
+    """Mask of the row-index errors kernels on `device` have met so far (include/spp.h SPP_AERR_*: 1 = a
+    serial_index / gather index outside its table, 2 = served id, 4 = assembly source); the kernels clamp such an
+    index to row 0 instead of faulting, so this is how a bad index surfaces.  A bit is visible once the offending
+    kernel has RUN: poll after a synchronising point (`.cpu()`, `synchronize()`)."""
+    dev = _device().index if device is None else torch.device(device).index
+    return int(_lib().spp_async_errors(int(dev or 0), 1 if clear else 0))
+
+
 def serial_index(inp: torch.Tensor, idx: torch.Tensor, n=None, pin_memory: bool = False) -> torch.Tensor:
-    """out[i,:] = in[idx[i],:] (fast_sampler.cpp:238-279); `n` limits/sets the output rows."""
+    """out[i,:] = in[idx[i],:] (fast_sampler.cpp:238-279); `n` limits/sets the output rows.  Asynchronous: an
+    index outside `inp` copies row 0 (the reference reads out of bounds) and raises SPP_AERR_GATHER_INDEX, which the
+    caller reads with async_errors() after its next synchronising point."""
     if isinstance(n, bool):                    # serial_index(in, idx, pin_memory) overload
         n, pin_memory = None, n
     if not ((inp.dim() == 2 and inp.stride(-1) == 1) or inp.size(-1) == 1):

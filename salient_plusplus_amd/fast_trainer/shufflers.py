@@ -53,6 +53,12 @@ class Shuffler:
         order = self._permutation().to(self.initial_idx.device)
         return self.initial_idx[order]
 
+    def __getstate__(self):
+        # the look-ahead holds a Thread: a pickled / copied shuffler simply recomputes its next permutation
+        state = dict(self.__dict__)
+        state["_ahead"] = None
+        return state
+
 
 class DistributedShuffler(Shuffler):
     """All ranks draw the same permutation; rank r trains on its r-th contiguous share of it."""

@@ -271,18 +271,26 @@ class _SageStack(torch.autograd.Function):
                 h = Z
             else:
                 out = torch.log_softmax(Z, dim=-1)
-        ctx.hops = hops
+        # tensors through save_for_backward (saved-tensor hooks, in-place version checks, a second backward with
+        # retain_graph all behave as autograd users expect); only ints and seeds live on ctx
+        hop_t = [t for (rowptr, col, _T) in hops for t in (rowptr, col)]
+        ctx.save_for_backward(*operands, *acts, *wcats, out, *hop_t)
+        ctx.hop_T = [int(T) for (_r, _c, T) in hops]
         ctx.act = (float(p), int(bool(training)), seeds)
-        ctx.saved = (operands, acts, wcats, out)
         ctx.src_rows = [x.size(0)] + [a.size(0) for a in acts]
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
         L = nat.load()
         st = _stream()
-        operands, acts, wcats, out = ctx.saved
-        n_layers = len(ctx.hops)
+        n_layers = len(ctx.hop_T)
+        sv = ctx.saved_tensors
+        operands, acts = sv[:n_layers], sv[n_layers:2 * n_layers - 1]
+        wcats, out = sv[2 * n_layers - 1:3 * n_layers - 1], sv[3 * n_layers - 1]
+        hop_t = sv[3 * n_layers:]
+        hops = [(hop_t[2 * i], hop_t[2 * i + 1], ctx.hop_T[i]) for i in range(n_layers)]
         gZ = torch._log_softmax_backward_data(g_out.contiguous(), out, -1, out.dtype)
         grads = [None] * (2 * n_layers)
         for i in range(n_layers - 1, -1, -1):
@@ -292,7 +300,7 @@ class _SageStack(torch.autograd.Function):
             grads[2 * i], grads[2 * i + 1] = gW[:, :K].contiguous(), gW[:, K:].contiguous()
             if i == 0:
                 break
-            rowptr, col, T = ctx.hops[i]
+            rowptr, col, T = hops[i]
             S = ctx.src_rows[i]
             gA = gZ @ W                                                         # [T, 2K]
             gH = torch.empty((S, K), dtype=torch.float32, device=gA.device)
@@ -310,7 +318,6 @@ class _SageStack(torch.autograd.Function):
                 nat.check(L.spp_relu_dropout_backward_pre(_p(gH), _p(acts[i - 1]), gH.numel(), p_, training_,
                                                           seeds[i - 1], _p(gH), st))
             gZ = gH
-        ctx.saved = None
         return (None, None, None, None, *grads)
 
 

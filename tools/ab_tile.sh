@@ -1,3 +1,6 @@
+#!/bin/bash
+# usage: tools/ab_tile.sh  (GPU box): workgroup size of the two tile kernels
+trap 'python3 -m salient_plusplus_amd.build > /dev/null 2>&1' EXIT   # back to the default flag set
 set -e
 for nt in 256 512 1024; do
   SPP_EXTRA_FLAGS="-DSPP_TILE_NT=$nt" python -m salient_plusplus_amd.build --force > /dev/null 2>&1
