@@ -1,0 +1,143 @@
+// Row-gather inner loop shared by k_gather_rows (gather.hip) and the fused k_deliver (sampler.hip).
+// A group of LPR lanes (power of two) moves one row with VEC-byte accesses; consecutive groups take
+// consecutive output rows so a wavefront's stores cover one contiguous span of dst, and every
+// group keeps kGatherUnroll independent rows in flight.  `vblock`/`nvblocks` are the calling
+// workgroup's index and the number of workgroups that share this gather (grid-stride).
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+
+namespace spp {
+
+template <int VEC> struct vec_of;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <> struct vec_of<16> { using type = u32x4; };
+template <> struct vec_of<8> { using type = u32x2; };
+template <> struct vec_of<4> { using type = uint32_t; };
+template <> struct vec_of<2> { using type = uint16_t; };
+template <> struct vec_of<1> { using type = uint8_t; };
+
+constexpr int kGatherThreads = 256;
+#ifndef SPP_GATHER_UNROLL
+#define SPP_GATHER_UNROLL 4
+#endif
+constexpr int kGatherUnroll = SPP_GATHER_UNROLL;
+
+struct GatherGeom {
+  int vec;        // bytes per lane access (16/8/4/2/1)
+  int chunks;     // row_bytes / vec
+  int lpr_log2;   // lanes per row (log2)
+  int64_t grid;   // workgroups wanted
+};
+
+static inline GatherGeom gather_geometry(const void* src, const void* dst, int64_t row_bytes, int64_t n,
+                                         int64_t src_stride = 0) {
+  GatherGeom g{};
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)row_bytes |
+                      (uintptr_t)src_stride;
+  g.vec = 16;
+  while (g.vec > 1 && (a % g.vec) != 0) g.vec >>= 1;
+  g.chunks = (int)(row_bytes / g.vec);
+  g.lpr_log2 = 0;
+  while ((1 << g.lpr_log2) < g.chunks && g.lpr_log2 < 6) ++g.lpr_log2;
+  const int gpb = kGatherThreads >> g.lpr_log2;
+  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
+  g.grid = (n + rows_per_iter - 1) / rows_per_iter;
+  static const int64_t max_grid = [] {  // 256 CUs x k workgroups: grid-stride beyond that
+    const char* e = getenv("SPP_GATHER_WG_PER_CU");
+    const int k = e ? atoi(e) : 16;
+    return (int64_t)256 * (k < 1 ? 1 : k);
+  }();
+  if (g.grid > max_grid) g.grid = max_grid;
+  if (g.grid < 1) g.grid = 1;
+  return g;
+}
+
+// kNT: non-temporal loads of the source rows.  Measured on MI355X (770k random 200-B rows of a
+// 490 MB table, sustained): plain loads 63 us, non-temporal loads 88-93 us -- the rows are not
+// really read-once (hub rows repeat across batches and MALL/L2 catch them), so plain is the default;
+// the stores stay non-temporal.
+// move_rows_body: dst[r,:] = *ptr_of(key_of(r)) for r < n.  The source of an output row comes in two steps so
+// that the loads of a round really are in flight together: key_of(r) is a pure load (an index, a source
+// record), ptr_of(key) turns it into the row's address (range checks, selects).  A single functor doing
+// both put control flow between the loads and the compiler waited for each before issuing the next.
+template <int VEC, bool kNT, typename KeyFn, typename PtrFn>
+__device__ __forceinline__ void move_rows_body(KeyFn key_of, PtrFn ptr_of, int64_t n, int64_t row_bytes, int chunks,
+                                               int lpr_log2, char* __restrict__ dst, int64_t vblock, int64_t nvblocks) {
+  using V = typename vec_of<VEC>::type;
+  const int lpr = 1 << lpr_log2;
+  const int g = threadIdx.x >> lpr_log2;
+  const int l = threadIdx.x & (lpr - 1);
+  const int gpb = kGatherThreads >> lpr_log2;  // row groups per workgroup
+  const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
+  const bool dense_lanes = chunks == lpr;
+  for (int64_t base = vblock * rows_per_iter; base < n; base += nvblocks * rows_per_iter) {
+    decltype(key_of((int64_t)0)) key[kGatherUnroll];
+    const V* s[kGatherUnroll];
+    V* d[kGatherUnroll];
+    bool ok[kGatherUnroll];
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) {
+      const int64_t r = base + (int64_t)u * gpb + g;
+      ok[u] = r < n;
+      key[u] = key_of(ok[u] ? r : n - 1);
+      d[u] = reinterpret_cast<V*>(dst + r * row_bytes);
+    }
+#pragma unroll
+    for (int u = 0; u < kGatherUnroll; ++u) s[u] = reinterpret_cast<const V*>(ptr_of(key[u]));
+    if (dense_lanes && base + rows_per_iter <= n) {  // workgroup-uniform: unconditional stores, no load sunk behind a predicate
+      V v[kGatherUnroll];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][l]) : s[u][l];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) __builtin_nontemporal_store(v[u], &d[u][l]);
+      continue;
+    }
+    for (int c = l; c < chunks; c += lpr) {
+      V v[kGatherUnroll];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
+#pragma unroll
+      for (int u = 0; u < kGatherUnroll; ++u)
+        if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);
+    }
+  }
+}
+
+template <int VEC, typename IdxT, bool kNT = false>
+__device__ __forceinline__ void gather_rows_body(const char* __restrict__ src, const IdxT* __restrict__ idx,
+                                                 int64_t n, int64_t row_bytes, int chunks, int lpr_log2,
+                                                 char* __restrict__ dst, int64_t vblock, int64_t nvblocks,
+                                                 int64_t src_stride) {
+  if (n <= 0) return;
+  move_rows_body<VEC, kNT>([=](int64_t r) { return idx[r]; }, [=](IdxT i) { return src + (int64_t)i * src_stride; }, n,
+                           row_bytes, chunks, lpr_log2, dst, vblock, nvblocks);
+}
+
+// Same with caller-supplied (untrusted) indices: an index outside [0, src_rows) reads row 0 and raises
+// SPP_AERR_GATHER_INDEX in `err` (the reference's serial_index would read out of bounds).
+template <int VEC, typename IdxT, bool kNT = false>
+__device__ __forceinline__ void gather_rows_checked_body(const char* __restrict__ src, int64_t src_rows,
+                                                         const IdxT* __restrict__ idx, int64_t n, int64_t row_bytes,
+                                                         int chunks, int lpr_log2, char* __restrict__ dst,
+                                                         int64_t vblock, int64_t nvblocks, int64_t src_stride,
+                                                         int32_t* err, int32_t err_bit) {
+  if (n <= 0) return;
+  move_rows_body<VEC, kNT>(
+      [=](int64_t r) { return idx[r]; },
+      [=](IdxT k) {
+        int64_t i = (int64_t)k;
+        if ((uint64_t)i >= (uint64_t)src_rows) {
+          if (err) __hip_atomic_fetch_or(err, err_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          i = 0;
+        }
+        return src + i * src_stride;
+      },
+      n, row_bytes, chunks, lpr_log2, dst, vblock, nvblocks);
+}
+
+}  // namespace spp

@@ -541,7 +541,7 @@ def main():
         dist.barrier()
         _trace("barrier passed, timing")
     torch.cuda.synchronize()
-    L.spp_profile_enable(1)
+    L.spp_profile_enable(0 if os.environ.get("SPP_BENCH_NO_PROF") == "1" else 1)
     # R windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides (the
     # closing bracket of a window is the opening bracket of the next, so the sampler's slots stay full
     # in between).  A single 20-step window is ~3 ms: its closing synchronize also waits for the refill

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPP_ABI_VERSION 3
+#define SPP_ABI_VERSION 4
 #define SPP_MAX_HOPS 8
 #define SPP_MAX_PARTS 64
 
@@ -324,6 +324,30 @@ spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
                               int64_t x_src_stride_bytes /* 0 = dense */, void* x_out_dev,
                               const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,
                               void* stream);
+/* Group-at-a-time consumption.  The batches of a sampling group (spp_session_group_size of them; fewer in
+ * the epoch's last group) become ready together, and delivering them with ONE launch keeps the delivery
+ * stream's hardware queue busy: a launch per batch cost ~25 us of queue idle time around every ~105 us kernel
+ * (completion signal, event markers, dispatch ramp), which bounded the whole pipeline.
+ *   spp_session_next_group: the descriptors of ALL batches of the next group (index order).  Returns 1 and
+ *     fills out[0 .. *n_out) when the group is sampled (and, with the native exchange, exchanged); 0 at the end
+ *     of the epoch; 2 when block == 0 and the group is not ready yet; < 0 on error.  With consumer-issued
+ *     exchanges (spp_exchange_cfg.issue_on_consumer) this is the program point at which the group's own exchange
+ *     -- and, with three or more slot-sets, the next group's -- is issued.
+ *   spp_session_export_group: writes the n batches returned by the last spp_session_next_group into caller
+ *     buffers with one launch on `stream` (per batch as spp_session_export: MFG, x = x_src[n_id] or the rows
+ *     assembled from the exchange, y = y_src[n_id[:stop-start]]), then recycles the group's slot-set.
+ * The per-batch calls (spp_session_next / spp_session_export) and the group calls may be mixed only at group
+ * boundaries. */
+typedef struct spp_group_out {
+  spp_mfg_out mfg;                 /* as spp_session_export's mfg (pointers may be NULL = skip) */
+  void* x_out;                     /* [U, x_row_bytes] dense, or NULL                           */
+  void* y_out;                     /* [stop - start, y_row_bytes], or NULL                      */
+} spp_group_out;
+int spp_session_next_group(spp_session* s, int32_t block, spp_batch_desc* out /* [group_size] */, int32_t* n_out);
+spp_status spp_session_export_group(spp_session* s, int32_t n, const spp_group_out* outs /* [n] */,
+                                    const void* x_src_dev, int64_t x_rows, int64_t x_row_bytes,
+                                    int64_t x_src_stride_bytes /* 0 = dense */,
+                                    const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* stream);
 /* total time spp_session_next spent blocked, microseconds, and number of blocking waits
  * (fast_sampler.cpp:788-799 total_blocked_dur / total_blocked_occasions) */
 int64_t spp_session_blocked_us(const spp_session* s);

@@ -40,6 +40,10 @@ class MfgOut(C.Structure):
                 ("parts", p), ("cached", p), ("perm", p)]
 
 
+class GroupOut(C.Structure):
+    _fields_ = [("mfg", MfgOut), ("x_out", p), ("y_out", p)]
+
+
 class ExchangeCfg(C.Structure):
     _fields_ = [("comm", p), ("x_local_dev", p), ("x_local_rows", i64), ("row_bytes", i64),
                 ("cache_feats_dev", p), ("cache_rows", i64), ("x_local_stride_bytes", i64),
@@ -96,6 +100,8 @@ SIGNATURES = {
     "spp_session_batch_ranges": (C.c_int, [p, p]),
     "spp_session_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
     "spp_session_export": (C.c_int, [p, C.POINTER(MfgOut), p, i64, i64, i64, p, p, i64, i64, p, p]),
+    "spp_session_next_group": (C.c_int, [p, i32, C.POINTER(BatchDesc), C.POINTER(i32)]),
+    "spp_session_export_group": (C.c_int, [p, i32, C.POINTER(GroupOut), p, i64, i64, i64, p, i64, i64, p]),
     "spp_session_blocked_us": (i64, [p]),
     "spp_session_blocked_occasions": (i64, [p]),
     "spp_session_sampler": (p, [p]),
@@ -155,7 +161,7 @@ def load():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.spp_abi_version() != 3:
+        if L.spp_abi_version() != 4:
             raise SppError("libspp_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -46,6 +46,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include <map>
@@ -1635,10 +1636,17 @@ struct DeliverArgs {
   int64_t recv_base[SPP_MAX_PARTS];
 };
 
+// The same for a whole GROUP of batches in ONE launch (spp_session_export_group).  A launch per batch left the
+// delivery stream's hardware queue idle for ~25 us around every kernel (completion signal, event markers, dispatch
+// ramp) -- at 105 us per delivery that, not the memory system, bounded the pipeline at ~0.14 ms per batch.
+// Workgroups [start[i], start[i+1]) work on batch i; its DeliverArgs are read from HBM (uniform loads).
+struct GroupBlocks {
+  int32_t n;
+  int32_t start[kMaxGroup + 1];
+};
+
 template <int VEC>
-__global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
-  static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
-  const int b = blockIdx.x;
+__device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
   if (b < a.nb_x) {
     if (!a.asm_on) {
       gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
@@ -1670,6 +1678,19 @@ __global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
       }
     }
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
+  static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
+  deliver_body<VEC>(a, (int)blockIdx.x);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kGatherThreads) void k_deliver_group(const DeliverArgs* __restrict__ args, GroupBlocks gb) {
+  int i = 0;
+  while (i + 1 < gb.n && (int)blockIdx.x >= gb.start[i + 1]) ++i;  // uniform: a handful of scalar compares
+  deliver_body<VEC>(args[i], (int)blockIdx.x - gb.start[i]);
 }
 
 }  // namespace spp
@@ -1761,7 +1782,9 @@ struct spp_sampler {
   std::unique_ptr<Worker> workers[2];  // persistent host threads lent to Sessions (sampler_worker)
   bool xcd_affinity = true;          // GroupGrid.interleave of the grouped launches (SPP_XCD_AFFINITY=0: batch-major ids)
   PartDev part{};                    // ownership bucketing (part.P == 0: off)
-  XBuf xbuf[kMaxWorkStreams];        // exchange buffers per slot-set (session.hip), kept across Sessions
+  DeliverArgs* dargs_host[kMaxSets] = {};  // per slot-set: pinned staging + device copy of a group delivery's arguments
+  DeliverArgs* dargs_dev[kMaxSets] = {};
+  XBuf xbuf[kMaxSets];               // exchange buffers per slot-set (session.hip), kept across Sessions
 };
 
 // layout of a slot's first-occurrence rank arrays for `cap` edge positions: [fbits | wpre | fsum] in one allocation
@@ -2093,6 +2116,10 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   for (auto st : s->work_streams)
     if (st) (void)hipStreamDestroy(st);
   if (s->comm_stream) (void)hipStreamDestroy(s->comm_stream);
+  for (auto& d : s->dargs_host)
+    if (d) (void)hipHostFree(d);
+  for (auto& d : s->dargs_dev)
+    if (d) (void)hipFree(d);
   for (auto& xb : s->xbuf) {
     if (xb.cnt_dev) (void)hipFree(xb.cnt_dev);
     if (xb.cnt_host) (void)hipHostFree(xb.cnt_host);
@@ -2282,6 +2309,19 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const int32_t interleave = s->xcd_affinity ? 1 : 0;
   auto GG = [&](unsigned gx) { return GroupGrid{(int32_t)first_slot, (int32_t)n, gx, interleave}; };
 
+  // Measurement aid (tools/ab_env.sh): SPP_WHATIF_DUP=count,pick,tiles,flag,rows launches the named (idempotent)
+  // kernels twice, so that the step time's increase is that kernel's cost IN SITU.  Results are unchanged.
+  static const struct Dup { int count, pick, tiles, flag, rows; } dup = [] {
+    Dup d{1, 1, 1, 1, 1};
+    if (const char* e = getenv("SPP_WHATIF_DUP")) {
+      if (strstr(e, "count")) d.count = 2;
+      if (strstr(e, "pick")) d.pick = 2;
+      if (strstr(e, "tiles")) d.tiles = 2;
+      if (strstr(e, "flag")) d.flag = 2;
+      if (strstr(e, "rows")) d.rows = 2;
+    }
+    return d;
+  }();
   const DedupGeom geom = s->geom;
   // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
   SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
@@ -2294,7 +2334,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
     // per-lane row staging of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
-    if (h > 0) {
+    for (int rep = 0; h > 0 && rep < dup.count; ++rep) {
       const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
       hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, h, f, replace, (int32_t)s->tcap[h]);
     }
@@ -2307,6 +2347,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     if (!self_prefix)
       hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     unsigned ge;
+    for (int rep = 0; !s->generic[h] && rep < dup.pick - 1; ++rep)
+      if (col32 && stubs)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
     if (!s->generic[h]) {
       if (col32 && stubs)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
@@ -2345,10 +2389,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
     // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
     const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
-    hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap);
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
-    hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap);
+    for (int rep = 0; rep < dup.tiles; ++rep) {  // (the histogram resets the cursors the scatter advanced: the pair is idempotent)
+      hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap);
+      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap);
+    }
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 12)
@@ -2358,10 +2404,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     else
       hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
-    hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
-                       (int32_t)s->tcap[H], pcap);
+    for (int rep = 0; rep < dup.flag; ++rep)
+      hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
+                         (int32_t)s->tcap[H], pcap);
     if (!s->generic[h]) {
-      hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
+      for (int rep = 0; rep < dup.rows; ++rep)
+        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];
@@ -2403,11 +2451,12 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   return SPP_OK;
 }
 
-// Fused delivery of the (waited) batch in `slot` on the caller's stream: MFG widening + x and y
-// row gathers in one launch.  Any of mfg / x / y may be absent.
-spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
-                           int64_t x_src_stride, void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows,
-                           void* y_dst, const AssembleSrc* asrc, hipStream_t st) {
+// Describes the delivery of the (waited) batch in `slot` -- MFG widening + x and y row gathers; any of mfg / x / y
+// may be absent -- as the workgroup ranges of one launch.  *vec: widest access all of its buffers allow.
+static spp_status fill_deliver_args(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src,
+                                    int64_t x_row_bytes, int64_t x_src_stride, void* x_dst, const void* y_src,
+                                    int64_t y_row_bytes, int64_t y_rows, void* y_dst, const AssembleSrc* asrc,
+                                    DeliverArgs& a, int* vec_out) {
   SlotHost& sl = s->slots[(size_t)slot];
   if (!sl.sampled || !sl.waited) {
     set_error("spp_session_export: slot %d must be sampled and waited first", slot);
@@ -2416,7 +2465,7 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   const SlotState* hs = sl.host_state;
   const int H = s->cfg.num_hops;
   const int64_t U = hs->cnt[H];
-  DeliverArgs a{};
+  a = DeliverArgs{};
   int n = 0;
   int64_t total = 0;
   auto add = [&](const int32_t* src, int64_t* dst, int64_t len) {
@@ -2446,7 +2495,7 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   a.segs.start[n] = total;
   a.n_ids = sl.p.n_ids;
   a.nb_e = total > 0 ? (int32_t)std::min<int64_t>(ceil_div(total, kNT), 1024) : 0;
-  int vec = 1;
+  int vec = 16;
   if (asrc) {
     SPP_REQUIRE(s->part.P > 0, "sampler_deliver: feature assembly needs ownership bucketing");
     x_src = asrc->x_local;
@@ -2489,6 +2538,18 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
     a.y_row_bytes = y_row_bytes;
     a.nb_y = (int32_t)std::min<int64_t>(ceil_div(ny, kNT), 64);
   }
+  *vec_out = vec;
+  return SPP_OK;
+}
+
+// Fused delivery of the (waited) batch in `slot` on the caller's stream in one launch.
+spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
+                           int64_t x_src_stride, void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows,
+                           void* y_dst, const AssembleSrc* asrc, hipStream_t st) {
+  DeliverArgs a;
+  int vec = 1;
+  SPP_TRY(fill_deliver_args(s, slot, mfg, x_src, x_row_bytes, x_src_stride, x_dst, y_src, y_row_bytes, y_rows, y_dst, asrc,
+                            a, &vec));
   const unsigned grid = (unsigned)(a.nb_x + a.nb_e + a.nb_y);
   if (grid == 0) return SPP_OK;
   const int prof = prof_begin(SPP_PROF_GATHER, st, a.x_rows);
@@ -2498,6 +2559,80 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
     case 4: hipLaunchKernelGGL(k_deliver<4>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
     case 2: hipLaunchKernelGGL(k_deliver<2>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
     default: hipLaunchKernelGGL(k_deliver<1>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+  }
+  prof_end(SPP_PROF_GATHER, prof, st);
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+// The same for the `n` (waited) batches in slots first_slot.. in ONE launch (k_deliver_group).  Their DeliverArgs
+// travel through a pinned staging record of the slot-set `set` and one small copy on `st`: the set's previous
+// delivery -- and with it the previous copy out of this staging record -- completed before the chain that filled
+// these slots could start, so the record is free.
+spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n, const spp_group_out* outs,
+                                 const void* x_src, int64_t x_row_bytes, int64_t x_src_stride, const void* y_src,
+                                 int64_t y_row_bytes, const int64_t* y_rows, const AssembleSrc* asrc /*[n] or NULL*/,
+                                 hipStream_t st) {
+  SPP_REQUIRE(n >= 1 && n <= kMaxGroup && set >= 0 && set < kMaxSets, "sampler_deliver_group: bad group");
+  if (!s->dargs_host[set]) {
+    SPP_HIP_TRY(hipHostMalloc((void**)&s->dargs_host[set], sizeof(DeliverArgs) * kMaxGroup, hipHostMallocDefault));
+    SPP_HIP_TRY(hipMalloc((void**)&s->dargs_dev[set], sizeof(DeliverArgs) * kMaxGroup));
+    s->bytes += (int64_t)sizeof(DeliverArgs) * kMaxGroup;
+  }
+  DeliverArgs* ha = s->dargs_host[set];
+  GroupBlocks gb{};
+  gb.n = n;
+  int vec = 16;
+  int64_t rows = 0, blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    int v = 16;
+    SPP_TRY(fill_deliver_args(s, first_slot + i, &outs[i].mfg, x_src, x_row_bytes, x_src_stride, outs[i].x_out, y_src,
+                              y_row_bytes, y_rows[i], outs[i].y_out, asrc ? &asrc[i] : nullptr, ha[i], &v));
+    vec = std::min(vec, v);
+    gb.start[i] = (int32_t)blocks;
+    blocks += ha[i].nb_x + ha[i].nb_e + ha[i].nb_y;
+    rows += ha[i].x_rows;
+  }
+  if (blocks == 0) return SPP_OK;
+  // Occupancy cap.  One launch covers the group, so without a cap its workgroups would hold every wave slot of the
+  // chip for the whole ~0.8 ms and the sampling chains of the next groups -- whose tile kernels need 16 free wave
+  // slots on ONE compute unit -- would starve behind it (k_bucket_hist of hop 1: 0.8 ms per launch).  The row
+  // gather is a grid-stride loop: SPP_DELIVER_WG_PER_CU workgroups (4 wavefronts each) per compute unit.
+  static const int wg_per_cu = [] {
+    const char* e = getenv("SPP_DELIVER_WG_PER_CU");
+    const int v = e ? atoi(e) : 6;
+    return v < 1 ? 1 : v;
+  }();
+  const int64_t cap_x = std::max<int64_t>(1, (int64_t)256 * wg_per_cu / n);
+  blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    ha[i].nb_x = (int32_t)std::min<int64_t>(ha[i].nb_x, cap_x);
+    ha[i].nb_e = (int32_t)std::min<int64_t>(ha[i].nb_e, 96);
+    ha[i].nb_y = (int32_t)std::min<int64_t>(ha[i].nb_y, 4);
+    gb.start[i] = (int32_t)blocks;
+    blocks += ha[i].nb_x + ha[i].nb_e + ha[i].nb_y;
+  }
+  gb.start[n] = (int32_t)blocks;
+  // a narrower access width than a batch was laid out for: its lanes-per-row geometry follows the common width
+  for (int i = 0; i < n; ++i) {
+    if (ha[i].nb_x == 0) continue;
+    const int chunks = (int)(ha[i].x_row_bytes / vec);
+    if (chunks != ha[i].x_chunks) {
+      int lpr = 0;
+      while ((1 << lpr) < chunks && lpr < 6) ++lpr;
+      ha[i].x_chunks = chunks;
+      ha[i].x_lpr_log2 = lpr;
+    }
+  }
+  SPP_HIP_TRY(hipMemcpyAsync(s->dargs_dev[set], ha, sizeof(DeliverArgs) * (size_t)n, hipMemcpyHostToDevice, st));
+  const int prof = prof_begin(SPP_PROF_GATHER, st, rows);
+  const DeliverArgs* da = s->dargs_dev[set];
+  switch (vec) {
+    case 16: hipLaunchKernelGGL(k_deliver_group<16>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    case 8: hipLaunchKernelGGL(k_deliver_group<8>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    case 4: hipLaunchKernelGGL(k_deliver_group<4>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    case 2: hipLaunchKernelGGL(k_deliver_group<2>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    default: hipLaunchKernelGGL(k_deliver_group<1>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
   }
   prof_end(SPP_PROF_GATHER, prof, st);
   SPP_HIP_TRY(hipGetLastError());
@@ -2524,7 +2659,7 @@ spp_status sampler_pack_remote_ids(spp_sampler* s, int first_slot, int n, const 
   return SPP_OK;
 }
 
-XBuf* sampler_xbuf(spp_sampler* s, int set) { return &s->xbuf[set % kMaxWorkStreams]; }
+XBuf* sampler_xbuf(spp_sampler* s, int set) { return &s->xbuf[set % kMaxSets]; }
 
 spp_status sampler_xbuf_grow(spp_sampler* s, void** buf, int64_t* cap, int64_t need, int64_t unit_bytes) {
   if (need <= *cap) return SPP_OK;

@@ -64,7 +64,8 @@ class Worker {
 Worker* sampler_worker(spp_sampler* s, int which);
 
 constexpr int kMaxGroup = 16;       // batches one launch can process (blockIdx.y)
-constexpr int kMaxWorkStreams = 4;  // sampling streams owned by a sampler (one per slot-set in flight)
+constexpr int kMaxWorkStreams = 4;  // sampling streams owned by a sampler (slot-sets share them round-robin)
+constexpr int kMaxSets = 8;         // slot-sets (groups sampled, exchanged or waiting for the consumer) in flight
 
 // largest group the sampler supports (1 when a hop takes the generic path)
 int sampler_max_group(const spp_sampler* s);
@@ -106,6 +107,12 @@ struct AssembleSrc {
 spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, const void* x_src, int64_t x_row_bytes,
                            int64_t x_src_stride, void* x_dst, const void* y_src, int64_t y_row_bytes, int64_t y_rows,
                            void* y_dst, const AssembleSrc* asrc, hipStream_t st);
+
+// The `n` waited batches of slot-set `set` (slots first_slot..) in ONE launch; outs[i] / y_rows[i] / asrc[i] belong to
+// batch i (asrc NULL: rows come from the one table x_src).
+spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n, const spp_group_out* outs,
+                                 const void* x_src, int64_t x_row_bytes, int64_t x_src_stride, const void* y_src,
+                                 int64_t y_row_bytes, const int64_t* y_rows, const AssembleSrc* asrc, hipStream_t st);
 
 // Ownership buckets of the batch in `slot` (valid once the group's completion event has been
 // synchronised): device arrays and the host mirror of the bucket sizes.

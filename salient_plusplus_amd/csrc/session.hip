@@ -106,6 +106,7 @@ struct spp_session {
   std::string launch_err;
   int64_t next_to_deliver = 0;           // batch index
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
+  int64_t current_group = -1;            // delivered by next_group(), not yet exported
   int64_t blocked_us = 0;
   int64_t blocked_occasions = 0;
   // native exchange (off when tr == nullptr)
@@ -580,7 +581,7 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 2));
   G = std::min(G, std::min(M, kMaxGroup));
   if (generic) G = 1;
-  int sets = std::max(1, std::min(M / G, kMaxWorkStreams));
+  int sets = std::max(1, std::min(M / G, kMaxSets));
 
   spp_status rc = SPP_OK;
   if (cfg->sampler) {
@@ -777,10 +778,29 @@ static spp_status issue_exchanges_up_to(spp_session* s, int64_t last_group) {
   return SPP_OK;
 }
 
+// row indices outside their table met by the exchange's kernels (spp_async_errors): reported once -- the bits are
+// cleared as they are read, so that a later Session on this device (another sampler, another communicator) does
+// not fail on a stale error of this one
+static spp_status check_exchange_errors(spp_session* s) {
+  int32_t* aw = async_err_word(s->cfg.device);
+  int32_t bits = aw ? __atomic_load_n(aw, __ATOMIC_ACQUIRE) : 0;
+  if (!(bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE))) return SPP_OK;
+  bits = __atomic_fetch_and(aw, ~(SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE), __ATOMIC_ACQ_REL);
+  if (!(bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE))) return SPP_OK;
+  set_error("feature exchange: a row outside its table was requested (async error mask %d: 2 = a peer asked this "
+            "rank for a row it does not own, 4 = assembly source out of range) -- the ranks disagree on the "
+            "partition book or the bucketing", bits);
+  return SPP_ERR_STATE;
+}
+
 extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
   if (!s || !out) {
     set_error("spp_session_next: NULL argument");
     return SPP_ERR_INVALID;
+  }
+  if (s->current_group >= 0) {
+    set_error("spp_session_next: a group returned by spp_session_next_group has not been exported");
+    return SPP_ERR_STATE;
   }
   if (s->current_slot >= 0) {  // previous batch was never exported: drop it
     spp_status rc = retire_current(s);
@@ -804,20 +824,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
     s->blocked_us += us;
     s->blocked_occasions++;
   }
-  if (rc == SPP_OK && s->tr) {
-    // reported once: the bits are cleared as they are read, so that a later Session on this device (another
-    // sampler, another communicator) does not fail on a stale error of this one
-    int32_t* aw = async_err_word(s->cfg.device);
-    int32_t bits = aw ? __atomic_load_n(aw, __ATOMIC_ACQUIRE) : 0;
-    if (bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE))
-      bits = __atomic_fetch_and(aw, ~(SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE), __ATOMIC_ACQ_REL);
-    if (bits & (SPP_AERR_SERVE_ID | SPP_AERR_ASSEMBLE)) {
-      set_error("feature exchange: a row outside its table was requested (async error mask %d: 2 = a peer asked this "
-                "rank for a row it does not own, 4 = assembly source out of range) -- the ranks disagree on the "
-                "partition book or the bucketing", bits);
-      rc = SPP_ERR_STATE;
-    }
-  }
+  if (rc == SPP_OK && s->tr) rc = check_exchange_errors(s);
   if (rc != SPP_OK) return rc;
   if (b % s->G == 0) trace_ev('G', g);
   out->batch_index = b;
@@ -887,6 +894,114 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
   s->export_recorded[(size_t)slot] = 1;
   return retire_current(s);
+}
+
+// ---- group-at-a-time consumption -------------------------------------------------------------------
+extern "C" int spp_session_next_group(spp_session* s, int32_t block, spp_batch_desc* out, int32_t* n_out) {
+  if (!s || !out || !n_out) {
+    set_error("spp_session_next_group: NULL argument");
+    return SPP_ERR_INVALID;
+  }
+  *n_out = 0;
+  if (s->current_slot >= 0 || s->current_group >= 0) {
+    set_error("spp_session_next_group: the previous batch / group has not been exported");
+    return SPP_ERR_STATE;
+  }
+  const int64_t nb = (int64_t)s->ranges.size();
+  if (s->next_to_deliver == nb) return 0;
+  if (s->next_to_deliver % s->G != 0) {
+    set_error("spp_session_next_group: batch %lld is in the middle of a group (mix per-batch and group calls only "
+              "at group boundaries)", (long long)s->next_to_deliver);
+    return SPP_ERR_STATE;
+  }
+  const int64_t g = s->next_to_deliver / s->G;
+  const int n = group_len(s, g);
+  const int32_t slot0 = (int32_t)((g % s->num_sets) * s->G);
+  if (!block) {
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (s->launch_rc == SPP_OK && s->exchange_rc == SPP_OK &&
+          (s->chain_launched <= g || (s->tr && !s->issue_on_consumer && s->exchange_launched <= g)))
+        return 2;
+    }
+    hipEvent_t ev = sampler_slot_event(s->sampler, slot0);
+    if (ev && hipEventQuery(ev) == hipErrorNotReady) return 2;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  trace_ev('N', g);
+  spp_status rc = wait_group_launched(s, g);
+  if (rc == SPP_OK && s->tr && s->issue_on_consumer)
+    // own group now and -- when a slot-set is to spare -- the next one, so that its transfers overlap the
+    // consumption of this group; always at THIS program point (every rank issues the same sequence)
+    rc = issue_exchanges_up_to(s, s->num_sets >= 3 ? g + 1 : g);
+  for (int i = 0; i < n && rc == SPP_OK; ++i) rc = spp_sampler_wait(s->sampler, slot0 + i, &out[i].counts);
+  if (rc == SPP_OK && s->tr) rc = wait_group_exchanged(s, g);
+  const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  if (us > 50) {
+    s->blocked_us += us;
+    s->blocked_occasions++;
+  }
+  if (rc == SPP_OK && s->tr) rc = check_exchange_errors(s);
+  if (rc != SPP_OK) return rc;
+  trace_ev('G', g);
+  for (int i = 0; i < n; ++i) {
+    const int64_t b = g * s->G + i;
+    out[i].batch_index = b;
+    out[i].start = s->ranges[(size_t)b].first;
+    out[i].stop = s->ranges[(size_t)b].second;
+    out[i].slot = slot0 + i;
+  }
+  s->current_group = g;
+  s->next_to_deliver += n;
+  *n_out = n;
+  return 1;
+}
+
+extern "C" spp_status spp_session_export_group(spp_session* s, int32_t n, const spp_group_out* outs, const void* x_src_dev,
+                                               int64_t x_rows, int64_t x_row_bytes, int64_t x_src_stride_bytes,
+                                               const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* stream) {
+  SPP_REQUIRE(s && outs, "spp_session_export_group: NULL argument");
+  if (s->current_group < 0) {
+    set_error("spp_session_export_group: no current group (call spp_session_next_group first)");
+    return SPP_ERR_STATE;
+  }
+  const int64_t g = s->current_group;
+  SPP_REQUIRE(n == group_len(s, g), "spp_session_export_group: the group holds %d batches, %d given", group_len(s, g), n);
+  (void)x_rows;
+  (void)y_rows;
+  const int set = (int)(g % s->num_sets);
+  const int32_t slot0 = (int32_t)(set * s->G);
+  int64_t bs[kMaxGroup];
+  for (int i = 0; i < n; ++i) {
+    const auto& r = s->ranges[(size_t)(g * s->G + i)];
+    bs[i] = (int64_t)r.second - r.first;
+  }
+  hipStream_t st = as_stream(stream);
+  if (s->tr) {
+    const XSet& x = s->xsets[(size_t)set];
+    SPP_HIP_TRY(hipStreamWaitEvent(st, x.rows_done, 0));
+    AssembleSrc src[kMaxGroup];
+    for (int i = 0; i < n; ++i) {
+      src[i] = AssembleSrc{};
+      src[i].x_local = static_cast<const char*>(s->xcfg.x_local_dev);
+      src[i].recv = x.b->recv_rows;
+      src[i].cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
+      src[i].x_local_stride = s->xcfg.x_local_stride_bytes;
+      src[i].cache_stride = s->xcfg.cache_stride_bytes;
+      for (int m = 0; m < s->P; ++m) src[i].recv_base[m] = x.recv_base[i][m];
+    }
+    SPP_TRY(sampler_deliver_group(s->sampler, set, slot0, n, outs, nullptr, s->xcfg.row_bytes, 0, y_src_dev, y_row_bytes, bs,
+                                  src, st));
+  } else {
+    SPP_TRY(sampler_deliver_group(s->sampler, set, slot0, n, outs, x_src_dev, x_row_bytes, x_src_stride_bytes, y_src_dev,
+                                  y_row_bytes, bs, nullptr, st));
+  }
+  // one event for the whole set: the chain that reuses it waits for this launch
+  SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot0], st));
+  s->export_recorded[(size_t)slot0] = 1;
+  s->current_group = -1;
+  notify_group_consumed(s, g + 1);
+  return SPP_OK;
 }
 
 extern "C" spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes) {

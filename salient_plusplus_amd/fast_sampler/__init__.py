@@ -16,6 +16,7 @@ Differences that follow from the MI355X design (documented in DESIGN.md):
     ``max_items_in_queue`` bounds the batch slots in flight.
 There is no CPU fallback: without the HIP extension and a GPU every entry point raises.
 """
+import collections
 import ctypes as C
 import datetime
 import os
@@ -418,6 +419,14 @@ class _SamplerPool:
             cls._pool.clear()
 
 
+def _coarse(n: int) -> int:
+    """n rounded up to a multiple of 2^(floor(log2 n) - 5): at most 3 % more, 32 sizes per octave"""
+    if n <= 64:
+        return max(n, 1)
+    g = 1 << (n.bit_length() - 6)
+    return (n + g - 1) // g * g
+
+
 def _host_ranges(n, batch_size, skip_nonfull, force_exact, exact_k):
     """fast_sampler.cpp:587-627 (only used to size the pooled sampler before the native session exists)."""
     if force_exact:
@@ -555,6 +564,14 @@ class Session:
             raise
         self._h = h
         self._desc = nat.BatchDesc()
+        # group-at-a-time delivery (include/spp.h spp_session_next_group / spp_session_export_group): the batches
+        # of a sampling group are written by ONE launch into three arenas and handed out one by one
+        self._group_mode = os.environ.get("SPP_GROUP_DELIVERY", "1") != "0"
+        self._gdescs = (nat.BatchDesc * 16)()
+        self._ready = collections.deque()          # (record, ready event, delivery stream) of delivered batches
+        self._ended = False
+        self.last_ready_event = None               # event after which the batch handed out last is complete
+        self._consumer_issue = bool(self.native_exchange and self._xc.issue_on_consumer)
         self._consumer_stream = None
         self._e_id = torch.empty(0, dtype=torch.int64, device=self._dev)
         # (src pointer, rows, row bytes) of the resident feature / label matrices, built once
@@ -603,6 +620,8 @@ class Session:
         self.close()
 
     def close(self):
+        if getattr(self, "_ready", None):
+            self._ready.clear()
         if getattr(self, "_h", None) is not None:
             try:                # the counters outlive the native session (get_stats() after the last batch)
                 self._final = {
@@ -644,7 +663,8 @@ class Session:
 
     @property
     def num_consumed_batches(self) -> int:
-        return int(self._L.spp_session_num_consumed_batches(self._h)) if self._h is not None else self._final["consumed"]
+        n = int(self._L.spp_session_num_consumed_batches(self._h)) if self._h is not None else self._final["consumed"]
+        return n - len(getattr(self, "_ready", ()))      # delivered to this object, not yet handed out
 
     @property
     def group_size(self) -> int:
@@ -728,9 +748,193 @@ class Session:
             return out, n_id, adjs, buckets
         return out, n_id, adjs
 
+    # ---- group-at-a-time delivery ----
+    def _fetch_group(self, block: bool) -> bool:
+        """Deliver the next sampling group: one allocation per output kind (int64 MFG arena, feature rows, labels),
+        ONE launch for all its batches, the records appended to self._ready.  False: not ready yet (block=False)
+        or no group left."""
+        if self._h is None or self._ended:
+            return False
+        n_c = C.c_int32(0)
+        rc = self._L.spp_session_next_group(self._h, 1 if block else 0, self._gdescs, C.byref(n_c))
+        nat.check(rc)
+        if rc == 2:
+            return False
+        if rc == 0:                                   # end of data: the sampler goes back to the pool once the queue is handed out
+            self._ended = True
+            if not self._ready:
+                self._finish()
+            return False
+        n = n_c.value
+        dev = self._dev
+        cfg = self.config
+        distributed = self._distributed
+        native = self.native_exchange
+        P = int(cfg.partition_book.world_size) if distributed else 0
+        rank = int(cfg.partition_book.rank) if distributed else 0
+        use_cache = bool(cfg.use_cache) if distributed else False
+        count_remote = distributed and bool(cfg.count_remote_frequency) and not use_cache
+        want_parts = distributed and (not native or count_remote or not self.compact_native_records)
+        want_n_id = distributed
+        want_x = (self._x is not None) and (native or not distributed)
+        want_y = self._y is not None
+        H = int(self._gdescs[0].counts.num_hops)
+        # ---- sizes (host counts of every batch) and the arena layout
+        seg = []                                      # lengths of all int64 segments, batch after batch
+        info = []
+        Us, bss = [], []
+        for i in range(n):
+            d = self._gdescs[i]
+            c = d.counts
+            U = int(c.num_nodes)
+            Ts = [int(c.T[k]) for k in range(H)]
+            Ss = [int(c.S[k]) for k in range(H)]
+            Es = [int(c.E[k]) for k in range(H)]
+            pc = [int(c.part_counts[m]) for m in range(P + 1)] if want_parts else None
+            first = len(seg)
+            if want_n_id:
+                seg.append(U)
+            for k in range(H):
+                seg.append(Ts[k] + 1)
+                seg.append(Es[k])
+            if want_parts:
+                seg.extend(pc[:P])
+                seg.append(pc[P])
+                seg.append(U)
+            info.append((first, U, Ts, Ss, Es, pc, int(d.start), int(d.stop)))
+            Us.append(U)
+            bss.append(int(d.stop) - int(d.start))
+        # arena sizes are rounded up to a coarse grid (<= 3 %): group totals differ by fractions of a percent from
+        # group to group, and the caching allocator would otherwise keep meeting sizes no cached block fits
+        n_seg = sum(seg)
+        arena = torch.empty(_coarse(n_seg), dtype=torch.int64, device=dev)
+        if seg:
+            seg.append(arena.numel() - n_seg)
+        views = arena.split(seg) if seg else ()
+        base = arena.data_ptr()
+        x_views = y_views = None
+        row_b = 0
+        if want_x:
+            F = self._x.size(1)
+            n_rows = sum(Us)
+            x_arena = torch.empty((_coarse(n_rows), F), dtype=self._x.dtype, device=dev)
+            x_views = x_arena.split(Us + [x_arena.size(0) - n_rows])
+            x_base, row_b = x_arena.data_ptr(), F * self._x.element_size()
+        if want_y:
+            y_arena = torch.empty((sum(bss), self._y.size(1)), dtype=self._y.dtype, device=dev)
+            y_views = y_arena.split(bss)
+            y_base, yrow_b = y_arena.data_ptr(), self._y.size(1) * self._y.element_size()
+        outs = (nat.GroupOut * n)()
+        e_id = self._e_id
+        off = 0                                       # running element offset into the int64 arena
+        xo = yo = 0
+        records = []
+        for i in range(n):
+            first, U, Ts, Ss, Es, pc, start, stop = info[i]
+            o = outs[i]
+            k = first
+            n_id = None
+            if want_n_id:
+                n_id = views[k]
+                o.mfg.n_id = (base + 8 * off) if U else None
+                off += U
+                k += 1
+            adjs = []
+            for h in range(H):
+                o.mfg.rowptr[h] = base + 8 * off
+                off += Ts[h] + 1
+                o.mfg.col[h] = (base + 8 * off) if Es[h] else None
+                off += Es[h]
+                adjs.append((views[k], views[k + 1], e_id, (Ts[h], Ss[h])))
+                k += 2
+            nids = flat = cached = perm = None
+            if want_parts:
+                owned = sum(pc[:P])
+                o.mfg.parts = (base + 8 * off) if owned else None
+                nids = list(views[k:k + P])
+                flat = arena[off:off + owned]
+                off += owned
+                k += P
+                cached = views[k]
+                o.mfg.cached = (base + 8 * off) if pc[P] else None
+                off += pc[P]
+                perm = views[k + 1]
+                o.mfg.perm = (base + 8 * off) if U else None
+                off += U
+            x = y = None
+            if want_x:
+                x = x_views[i]
+                o.x_out = (x_base + xo * row_b) if U else None
+                xo += U
+            if want_y:
+                y = y_views[i]
+                o.y_out = (y_base + yo * yrow_b) if bss[i] else None
+                yo += bss[i]
+            records.append((x, y, adjs, (start, stop), n_id, nids, flat, cached, perm, pc, U))
+        stream = torch.cuda.current_stream(dev)
+        xa = self._x_args if (want_x and not native) else (None, 0, 0, 0)
+        ya = self._y_args if want_y else (None, 0, 0)
+        nat.check(self._L.spp_session_export_group(self._h, n, outs, xa[0], xa[1], xa[2], xa[3], ya[0], ya[1], ya[2],
+                                                   C.c_void_p(stream.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for (x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, U) in records:
+            if not distributed:
+                if x is None:
+                    x = torch.empty((U, 0), device=dev)
+                rec = (x, y, adjs, rng)
+            else:
+                rec = self._proto_record(x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank)
+            self._ready.append((rec, ev, stream))
+        return True
+
+    def _proto_record(self, x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank):
+        b = ProtoDistributedBatch()
+        feat_dim = self._x.size(1) if self._x is not None else 0
+        feat_dtype = self._x.dtype if self._x is not None else torch.float16
+        if nids is None:                               # compact native record: only what this repository's iterator reads
+            nids, flat = [], None
+            cached = perm = torch.empty(0, dtype=torch.int64, device=self._dev)
+        b.x = x if native else None
+        b.partition_nids = nids
+        b.partition_nids_flat = flat
+        b.cached_nids = cached
+        b.perm_partition_to_mfg = perm
+        if pc is not None:
+            b.partition_counts = pc
+        b.sliced_cpu_features = torch.empty((0, feat_dim), dtype=feat_dtype)   # all local rows are in HBM
+        b.sliced_cpu_labels = y if y is not None else torch.zeros(0)
+        b.adjs = adjs
+        b.idx_range = rng
+        b.n_id = n_id
+        if count_remote:
+            self._count_remote(b.partition_nids, rank)
+        return b
+
+    def _pop_ready(self, block: bool):
+        """Hand out the next delivered batch; keeps one group delivered AHEAD of the one being handed out, so that
+        its (single) delivery launch overlaps the consumption of this one."""
+        if not self._ready and not self._fetch_group(block):
+            return None
+        rec, ev, stream = self._ready.popleft()
+        self.last_ready_event = ev
+        cur = torch.cuda.current_stream(self._dev)
+        if cur != stream:                              # delivered on another stream than the caller is on now
+            cur.wait_event(ev)
+        G = self.group_size
+        if len(self._ready) < G and not self._ended:
+            # consumer-issued exchanges: always at this program point, blocking (every rank issues the same
+            # sequence of collectives); otherwise opportunistic
+            self._fetch_group(self._consumer_issue)
+        if self._ended and not self._ready:
+            self._finish()
+        return rec
+
     def blocking_get_batch(self, _block=True):
         """-> None or (x, y-or-None, [(rowptr, col, e_id, (T, S)) ...], (start, stop))
         (worker non-distributed branch, fast_sampler.cpp:1004-1016)."""
+        if self._group_mode:
+            return self._pop_ready(_block)
         if not self._next_desc(_block):
             return None
         d = self._desc
@@ -761,6 +965,14 @@ class Session:
 
     def blocking_get_batch_distributed(self, _block=True):
         """-> None or ProtoDistributedBatch (worker distributed branch, fast_sampler.cpp:1017-1272)."""
+        if self._group_mode:
+            b = self._pop_ready(_block)
+            if b is not None and self.native_exchange and not self.compact_native_records:
+                # at most the two newest batches (double buffering); a consumer that never asks loses nothing
+                while len(self._native_feats) >= 2:
+                    self._native_feats.pop(next(iter(self._native_feats)))
+                self._native_feats[b.idx_range] = (b.x, b.n_id)
+            return b
         if not self._next_desc(_block):
             return None
         d = self._desc

@@ -6,19 +6,18 @@ a device synchronise, ``print_stats()``, ``NUMBER_OF_SENT_BYTES``.
 
 MI355X re-design of the distributed iterator.  The reference runs a 10-stage pipeline with three
 list-form NCCL all_to_alls, two forced D2H syncs, host-side slicing of host-resident rows and a
-zeros+scatter+cat+permute assembly (~4x the algorithmic feature bytes).  Here every feature row of
-the rank is HBM resident, the sampler already produced the ownership buckets on the GPU, and a batch
-needs only:
+zeros+scatter+cat+permute assembly (~4x the algorithmic feature bytes) PER BATCH.  Here every feature row of
+the rank is HBM resident and the sampler already produced the ownership buckets on the GPU, so:
 
-   B  counts  : one all_to_all_single of P int64 (split sizes for the next two exchanges)
-   C  ids     : one all_to_all_single of the requested node ids (variable splits)
-   D  serve   : one row gather  x_local[ids - offset]  straight into the send buffer
-   E  rows    : one all_to_all_single of feature rows over xGMI (own slot empty)
-   F  assemble: one fused kernel writing x in MFG order from {local rows, cache rows, received rows}
-
-The stages of consecutive batches are software-pipelined (newest stage first, like
-transferers.py:399-421) on one side stream, so the only host wait -- reading the P received counts --
-is on a collective issued one iteration earlier.
+  * native transport (default with an NCCL/RCCL process group): the Session runs ONE exchange per GROUP of
+    batches below the C ABI (all-gather of the request counts, grouped send/recv of int32 ids, one row gather,
+    grouped send/recv of the rows; csrc/session.hip) and delivers the whole group -- MFG, labels and x assembled
+    from {local partition, received rows, VIP cache} -- with one launch.  This iterator then only double-buffers:
+    it hands out the batch fetched during the previous call and waits for that batch's group event;
+  * torch.distributed transport (SPP_DIST_TRANSPORT=torch, non-NCCL backends, reference-shaped producers): the
+    same exchange with `all_to_all_single`, also once per group of batches (counts [P x G], ids and rows
+    peer-major across the group's batches, one fused assembly kernel per batch), software-pipelined two groups
+    deep on one side stream: counts of group g+2, ids/serve/rows of group g+1, assembly of group g.
 """
 import ctypes as C
 import time
@@ -47,6 +46,11 @@ class DeviceIterator(Iterator[List[PreparedBatch]]):
 
 def _is_cuda(device) -> bool:
     return torch.device(device).type == "cuda"
+
+
+def _ready_event(it):
+    """the event after which the batch `it` returned last is complete (GPU Session: one per delivered group), or None"""
+    return getattr(getattr(it, "session", None), "last_ready_event", None)
 
 
 class _HipFeatureOps:
@@ -177,6 +181,7 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.q_rows = deque()      # groups whose row exchange is in flight
         self.ready = deque()       # assembled batches of the current group
         self.next: Optional[list] = []
+        self.next_event = None
         self.NUMBER_OF_SENT_BYTES = 0
         self.ITERATION = 0
         self._exhausted = False
@@ -314,6 +319,7 @@ class DeviceDistributedPrefetcher(DeviceIterator):
                 runtime_stats_cuda.start_region("sampling2")
                 proto = next(self.it, None)
                 runtime_stats_cuda.end_region("sampling2")
+                self.next_event = _ready_event(self.it) if proto is not None else None
                 if proto is None:
                     self.next = None
                     sent, _recv = self.it.session.exchange_bytes()
@@ -352,7 +358,10 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.ITERATION += 1
         runtime_stats_cuda.start_region("data_transfer", runtime_stats_cuda.get_last_event())
         if self.side.cuda:
-            torch.cuda.current_stream(self.device).wait_stream(self.side.stream)
+            if self.native and self.next_event is not None:      # this batch's group, not the one queued behind it
+                torch.cuda.current_stream(self.device).wait_event(self.next_event)
+            else:
+                torch.cuda.current_stream(self.device).wait_stream(self.side.stream)
         runtime_stats_cuda.end_region("data_transfer")
         runtime_stats_cuda.start_region("sampling", runtime_stats_cuda.get_last_event())
         if not ret:
@@ -398,11 +407,13 @@ class DevicePrefetcher(DeviceIterator):
         # from the sampling streams); otherwise a plain side stream as in the reference
         self.streams = [sess_stream] if sess_stream is not None else [torch.cuda.Stream(device) for device in devices]
         self.next = []
+        self.next_events = []
         self.sampling_times = []
         self.preload(False)
 
     def preload(self, timing=True):
         self.next = []
+        self.next_events = []
         for device, stream in zip(self.devices, self.streams):
             t0 = time.perf_counter_ns()
             with torch.cuda.stream(stream):
@@ -412,13 +423,21 @@ class DevicePrefetcher(DeviceIterator):
                 # batches of the GPU sampler are already in HBM: `.to` would only rebuild the records
                 on_dev = batch.x is not None and batch.x.is_cuda and batch.x.device == torch.device(device)
                 self.next.append(batch if on_dev else batch.to(device, non_blocking=True))
+                # The GPU sampler delivers a whole group of batches with one launch and names the event after
+                # which THIS batch is complete: waiting for that event instead of the whole side stream keeps
+                # the model from waiting for the delivery of the group after it (already queued on the stream).
+                self.next_events.append(_ready_event(self.it) if on_dev else None)
             self.sampling_times.append(time.perf_counter_ns() - t0)
 
     def __next__(self):
         runtime_stats_cuda.start_region("data_transfer", runtime_stats_cuda.get_last_event())
         cur_streams = [torch.cuda.current_stream(device) for device in self.devices]
-        for cur_stream, stream in zip(cur_streams, self.streams):
-            cur_stream.wait_stream(stream)
+        for k, (cur_stream, stream) in enumerate(zip(cur_streams, self.streams)):
+            ev = self.next_events[k] if k < len(self.next_events) else None
+            if ev is not None:
+                cur_stream.wait_event(ev)
+            else:
+                cur_stream.wait_stream(stream)
         runtime_stats_cuda.end_region("data_transfer")
         runtime_stats_cuda.start_region("sampling", runtime_stats_cuda.get_last_event())
         ret = self.next

@@ -82,7 +82,7 @@ def test_ddp_training_steps_between_consumer_issued_exchanges(nccl_world1, monke
             loss = torch.nn.functional.nll_loss(ddp(batch.x, batch.adjs), batch.y.reshape(-1))
             loss.backward()                    # gradient all-reduce on the torch group
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         pre.quiesce()
         it.session.close()
     assert np.isfinite(losses).all()

@@ -1,0 +1,171 @@
+"""-m gpu: group-at-a-time delivery (include/spp.h spp_session_next_group / spp_session_export_group).
+
+The batches of a sampling group are written by ONE launch into caller arenas.  Checked here: the group path and
+the per-batch path (spp_session_next / spp_session_export) deliver identical batches and both agree with the
+reference fixtures; the two call families mix at group boundaries and refuse to mix inside a group; the ready
+event an iterator waits for belongs to the batch's own group."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fs():
+    from salient_plusplus_amd import fast_sampler
+    return fast_sampler
+
+
+def _cfg(fs, g, sizes, bs, x=None, **kw):
+    from salient_plusplus_amd.fast_trainer.samplers import FastSamplerConfig
+    T = torch.from_numpy
+    x = g["x"] if x is None else x
+    d = dict(x_cpu=T(x), x_gpu=torch.empty(0), y=T(g["y"]).unsqueeze(-1), rowptr=T(g["rowptr"]), col=T(g["col"]),
+             idx=T(g["idx"]), batch_size=bs, sizes=list(sizes), skip_nonfull_batch=False, pin_memory=False,
+             distributed=False, partition_book=None, cache=fs.Cache(), force_exact_num_batches=False,
+             exact_num_batches=0, count_remote_frequency=False, use_cache=False)
+    d.update(kw)
+    return FastSamplerConfig(**d)
+
+
+def _collect(fs, cfg, slots):
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    out = []
+    for b in iter(FastSampler(2, slots, cfg)):
+        out.append((b.x.cpu(), b.y.cpu(), [(a.adj_t.csr()[0].cpu(), a.adj_t.csr()[1].cpu(), tuple(a.size)) for a in b.adjs],
+                    (b.idx_range.start, b.idx_range.stop)))
+    return out
+
+
+@pytest.mark.parametrize("sizes,bs,slots", [([15, 10, 5], 16, 32), ([25, 15], 8, 8), ([3, -1], 32, 4), ([5], 7, 16)])
+def test_group_path_equals_per_batch_path_and_the_oracle(fs, graph_a, sizes, bs, slots, monkeypatch):
+    """ragged last groups, 1..8 batches per group, the generic (one batch per group) sampling path"""
+    from oracle import oracle as orc
+    cfg = _cfg(fs, graph_a, sizes, bs)
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", "1")
+    grouped = _collect(fs, cfg, slots)
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", "0")
+    single = _collect(fs, cfg, slots)
+    assert len(grouped) == len(single) == -(-len(graph_a["idx"]) // bs)
+    for k, (a, b) in enumerate(zip(grouped, single)):
+        assert a[3] == b[3]
+        assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1], b[1])
+        m = orc.sample_batch(graph_a["rowptr"], graph_a["col"], graph_a["idx"], a[3][0], a[3][1], sizes)
+        np.testing.assert_array_equal(a[0].numpy().view(np.uint16), graph_a["x"][m.n_id].view(np.uint16))
+        for (rp, cl, size), (rp2, cl2, size2), hop in zip(a[2], b[2], m.hops):
+            assert size == size2 and torch.equal(rp, rp2) and torch.equal(cl, cl2)
+            np.testing.assert_array_equal(rp.numpy(), hop.rowptr)
+            np.testing.assert_array_equal(cl.numpy(), hop.col)
+
+
+def test_group_and_batch_calls_mix_only_at_group_boundaries(fs, graph_a):
+    """straight through the C ABI: group 0 by next_group / export_group, group 1 batch by batch, group 2 grouped again"""
+    from oracle import oracle as orc
+    from salient_plusplus_amd import _native as nat
+    L = nat.load()
+    dev = torch.device("cuda", 0)
+    g = graph_a
+    sizes, bs = [4, 3], 8
+    nb = 20
+    idx = torch.from_numpy(g["idx"][:nb * bs]).to(dev)
+    rowptr, col = torch.from_numpy(g["rowptr"]).to(dev), torch.from_numpy(g["col"]).to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    row_b = x.size(1) * 2
+    cfg = nat.SessionCfg()
+    cfg.rowptr_dev, cfg.col_dev = rowptr.data_ptr(), col.data_ptr()
+    cfg.num_nodes, cfg.nnz = rowptr.numel() - 1, col.numel()
+    cfg.idx_dev, cfg.n_idx, cfg.batch_size, cfg.num_hops = idx.data_ptr(), idx.numel(), bs, len(sizes)
+    for i, s_ in enumerate(sizes):
+        cfg.sizes[i] = s_
+    cfg.max_items_in_queue, cfg.group_size, cfg.device = 8, 4, 0
+    torch.cuda.synchronize()
+    h = C.c_void_p()
+    nat.check(L.spp_session_create(C.byref(cfg), C.byref(h)))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    G = L.spp_session_group_size(h)
+    assert G == 4
+    descs = (nat.BatchDesc * 16)()
+    n = C.c_int32(0)
+    keep = []
+
+    def check(desc, xs, n_id):
+        m = orc.sample_batch(g["rowptr"], g["col"], g["idx"][:nb * bs], int(desc.start), int(desc.stop), sizes)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(n_id.cpu().numpy(), m.n_id)
+        np.testing.assert_array_equal(xs.cpu().numpy().view(np.uint16), g["x"][m.n_id].view(np.uint16))
+
+    def grouped():
+        assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == 1
+        outs = (nat.GroupOut * n.value)()
+        bufs = []
+        for i in range(n.value):
+            U = int(descs[i].counts.num_nodes)
+            xs = torch.empty((U, x.size(1)), dtype=x.dtype, device=dev)
+            n_id = torch.empty(U, dtype=torch.int64, device=dev)
+            outs[i].x_out, outs[i].mfg.n_id = xs.data_ptr(), n_id.data_ptr()
+            bufs.append((xs, n_id))
+        # a per-batch call while the group is pending is a call-sequence error
+        d1 = nat.BatchDesc()
+        assert L.spp_session_next(h, C.byref(d1)) == -4
+        nat.check(L.spp_session_export_group(h, n.value, outs, x.data_ptr(), x.size(0), row_b, 0, None, 0, 0, st))
+        for i in range(n.value):
+            check(descs[i], *bufs[i])
+        keep.append(bufs)
+        return n.value
+
+    def single():
+        d = nat.BatchDesc()
+        assert L.spp_session_next(h, C.byref(d)) == 1
+        U = int(d.counts.num_nodes)
+        xs = torch.empty((U, x.size(1)), dtype=x.dtype, device=dev)
+        n_id = torch.empty(U, dtype=torch.int64, device=dev)
+        out = nat.MfgOut()
+        out.n_id = n_id.data_ptr()
+        nat.check(L.spp_session_export(h, C.byref(out), x.data_ptr(), x.size(0), row_b, 0, xs.data_ptr(), None, 0, 0, None, st))
+        check(d, xs, n_id)
+
+    try:
+        assert grouped() == 4
+        single()
+        # in the middle of a group the group call is refused
+        assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == -4
+        for _ in range(3):
+            single()
+        assert grouped() == 4
+        assert grouped() == 4
+        assert grouped() == 4                              # 20 batches = 5 groups of 4
+        assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == 0
+        assert L.spp_session_num_consumed_batches(h) == nb
+    finally:
+        L.spp_session_destroy(h)
+
+
+def test_ready_event_belongs_to_the_batchs_own_group(fs, graph_a):
+    """DevicePrefetcher waits for the event of the group the batch came from, and the look-ahead keeps the NEXT
+    group's delivery queued behind it: every batch must be complete when its event has fired."""
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    from salient_plusplus_amd.fast_trainer.transferers import DevicePrefetcher
+    dev = torch.device("cuda", 0)
+    n = graph_a["rowptr"].shape[0] - 1
+    ids_as_x = np.arange(n, dtype=np.float32).reshape(n, 1)
+    cfg = _cfg(fs, graph_a, [6, 4], 8, x=ids_as_x)
+    it = iter(FastSampler(2, 16, cfg))
+    pre = DevicePrefetcher([dev], it)
+    events = set()
+    nb = 0
+    for (batch,) in pre:
+        ev = it.session.last_ready_event
+        assert ev is not None
+        events.add(id(ev))
+        nb += 1
+    assert nb == -(-len(graph_a["idx"]) // 8)
+    assert len(events) >= 2        # one event per delivered group, shared by its batches
