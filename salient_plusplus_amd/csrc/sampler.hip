@@ -164,6 +164,7 @@ __device__ __forceinline__ RankWord load_rank_word(const SPP_GLOBAL RankWord* p,
 
 struct SlotPtrs {
   int32_t* n_ids;
+  uint8_t* dtag;       // [Ucap] min(degree, cap) of every node of the list (degree-tagged neighbour ids; NULL: off)
   int32_t* deg;
   int64_t* rowstart;
   int32_t* cval;       // neighbour node id of every edge position (later: local id, generic path)
@@ -301,6 +302,37 @@ __global__ __launch_bounds__(256) void k_narrow_col(const int64_t* __restrict__ 
     out[i] = (int32_t)col[i];
 }
 
+// Degree-tagged neighbour ids.  Node ids need idbits = ceil(log2 num_nodes) bits (27 for 111 M nodes); the spare top
+// bits of every entry of the int32 neighbour array -- and of the row stubs copied from it -- carry
+// min(degree of that neighbour, cap), cap = 2^(32 - idbits) - 1.  A hop's degree pass only decides "all neighbours or
+// f picks" and counts edges, for which min(degree, cap) is exact while cap > f: the nodes a hop discovers then bring
+// their own degree along, and the NEXT hop's degree pass is a sequential read of one byte per target instead of one
+// random 128-byte line per target (25 MB of the chain's 143 MB per batch, 5.6 us of a 137 us step).  The exact degree
+// and the row start a sampled row needs come out of the stub line k_hop_pick fetches anyway.  Built once per graph:
+// a saturated-degree byte per node (sequential), then one random byte read per edge (0.2 s for 3.2 G edges).
+__global__ __launch_bounds__(256) void k_build_deg8(const int64_t* __restrict__ rowptr, int64_t num_nodes,
+                                                    uint8_t* __restrict__ out) {
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < num_nodes; v += (int64_t)gridDim.x * 256) {
+    const int64_t d = rowptr[v + 1] - rowptr[v];
+    out[v] = (uint8_t)(d > 255 ? 255 : (d < 0 ? 0 : d));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_narrow_col_tagged(const int64_t* __restrict__ col, int64_t nnz,
+                                                           const uint8_t* __restrict__ deg8, int32_t idbits, uint32_t cap,
+                                                           int32_t* __restrict__ out) {
+  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < nnz; i0 += (int64_t)gridDim.x * 256 * 4) {
+    uint32_t c[4], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (uint32_t)col[i0 + u < nnz ? i0 + u : nnz - 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = deg8[c[u]];  // the four random byte reads in flight together
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u < nnz) out[i0 + u] = (int32_t)(c[u] | ((d[u] < cap ? d[u] : cap) << idbits));
+  }
+}
+
 // Row stubs: one 128-byte, 128-byte-aligned record per node -- {degree, row start (lo, hi), the first 29
 // neighbours} -- built once per graph.  A sampled row's degree AND (for most rows) every neighbour the
 // picks can name then sit in ONE cache line at a computable address: k_hop_count / k_seed_init read the
@@ -366,7 +398,8 @@ __device__ __forceinline__ void target_counts(int32_t deg, int32_t f, int32_t re
 // chain starts with one launch instead of two.
 __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ slots, GroupArgs ga, DedupGeom g,
                                                     const int64_t* __restrict__ rowptr,
-                                                    const stub4* __restrict__ stubs, int32_t f, int32_t replace) {
+                                                    const stub4* __restrict__ stubs, int32_t f, int32_t replace,
+                                                    uint32_t tag_cap) {
   SPP_GROUP_BLOCK(ga.grid);
   __shared__ int32_t lds[2][kNT / kWave + 1];
   const SlotPtrs& s = slots[ga.first_slot + by_];
@@ -393,6 +426,7 @@ __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ 
     else atomicOr(&s.st->error, kErrBucketCap);
     s.deg[i] = deg;
     s.rowstart[i] = rs;
+    if (tag_cap) s.dtag[i] = (uint8_t)((uint32_t)deg < tag_cap ? (uint32_t)deg : tag_cap);
     target_counts(deg, f, replace, cnt, smp);
   }
   int32_t tc, ts;
@@ -435,8 +469,8 @@ __device__ __forceinline__ bool take_ticket_is_last(int32_t* ctr, int32_t expect
 // compiler wait for it before it issues the next one.
 __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                     const int64_t* __restrict__ rowptr,
-                                                    const stub4* __restrict__ stubs, int32_t h, int32_t f,
-                                                    int32_t replace, int32_t tcap) {
+                                                    const stub4* __restrict__ stubs, int32_t use_tags,
+                                                    int32_t h, int32_t f, int32_t replace, int32_t tcap) {
   SPP_GROUP_BLOCK(gg);
   constexpr int kPer = kNT / kWave;  // targets per lane
   const SlotPtrs& s = slots[gg.first_slot + by_];
@@ -458,6 +492,15 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
     v[u] = n_ids[ic];
     deg[u] = degp[ic];  // a target of the previous hop as well: its degree and row start are still in place
   }
+  uint8_t tg[kPer];
+  if (use_tags) {  // the nodes' own degree tags, written next to n_ids by the hop that discovered them: sequential
+    const SPP_GLOBAL uint8_t* dtag = G(s.dtag);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int64_t i = i0 + u * kWave + lane;
+      tg[u] = dtag[i < tcap ? i : tcap - 1];
+    }
+  }
   if (i0 >= T) return;
   int64_t rs[kPer];
   int32_t nd[kPer];
@@ -468,7 +511,13 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
     fresh[u] = i < T && i >= Tprev;
     if (!fresh[u]) v[u] = 0;
   }
-  if (stubs) {
+  if (use_tags) {  // the row start is not needed: k_hop_pick takes it (and the exact degree) from the stub line
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      nd[u] = tg[u];
+      rs[u] = 0;
+    }
+  } else if (stubs) {
     stub4 hd[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) hd[u] = stubs[(int64_t)v[u] * 8];
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(kNT) void k_hop_count(const SlotPtrs* __restrict__ 
     if (fresh[u]) {
       deg[u] = nd[u];
       degp[i] = nd[u];
-      rsp[i] = rs[u];
+      if (!use_tags) rsp[i] = rs[u];
     }
     if (i < T) {
       int32_t c, m;
@@ -547,12 +596,14 @@ __global__ __launch_bounds__(kScanNT) void k_hop_scan(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 // picks + col reads + node-table insert (fast path: 0 <= fanout <= 32)
 // ----------------------------------------------------------------------------------------------
-template <bool kGeneric, typename ColT, bool kStub>
+template <bool kGeneric, typename ColT, bool kStub, bool kHdr = false>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                    const ColT* __restrict__ col, const stub4* __restrict__ stubs,
                                                    int32_t h, int32_t f,
                                                    int32_t replace, int32_t self_prefix, int32_t ecap, int64_t dcap,
-                                                   int32_t tcap) {
+                                                   int32_t tcap, uint32_t pick_mask) {
+  // pick_mask: applied to every neighbour entry read from the int32 array / the stubs -- all ones when the degree
+  // tags travel on (or the entries carry none), the id mask when they are tagged but this sampler does not use them
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lds_scan[2][kNT / kWave + 1];
   // Floyd picks of the row, one column per lane: f rows of kNT ints, sized by the launch (dynamic LDS) --
@@ -572,8 +623,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   const int32_t err0 = st->error;
   const int64_t dbase = st->dbase[h];
   const uint32_t* rng_gen = st->rng;
+  // kHdr: s.deg holds min(degree, 255) (k_hop_count read the byte array) -- enough for the counts below; the exact
+  // degree and the row start come out of the row's stub line once it has arrived
   int32_t deg = G(s.deg)[ic];
-  int64_t rs = G(s.rowstart)[ic];
+  int64_t rs = kHdr ? 0 : G(s.rowstart)[ic];
   int32_t vnode = kStub ? G(s.n_ids)[ic] : 0;
   // Offsets of this workgroup's targets: the sums of the workgroups before it.  With self_prefix the
   // workgroup adds up their per-workgroup sums (k_hop_count) itself -- at most a few loads per lane --
@@ -630,6 +683,25 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
                              (uint32_t)__shfl((int32_t)(uint32_t)rs, src, kWave);
         seg[r] = (part * 4 < len_r) ? *reinterpret_cast<const i4u*>(col + rs_r + part * 4) : i4{0, 0, 0, 0};
       }
+    }
+  }
+  if constexpr (kCoop && kHdr) {
+    // header {degree, row start lo, hi} of lane L's row: words 0..2 of the piece lane (L & 7) * 8 holds in round L >> 3
+    const int lane = threadIdx.x & (kWave - 1);
+    const int src = (lane & 7) * 8;
+    int32_t hd = 0, hlo = 0, hhi = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int32_t d = __shfl(seg[r].x, src, kWave), lo = __shfl(seg[r].y, src, kWave), hi = __shfl(seg[r].z, src, kWave);
+      if ((lane >> 3) == r) {
+        hd = d;
+        hlo = lo;
+        hhi = hi;
+      }
+    }
+    if (i < T) {
+      deg = hd;
+      rs = ((int64_t)hhi << 32) | (uint32_t)hlo;
     }
   }
   int32_t pre0, pre1, tot0, tot1;
@@ -714,7 +786,9 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     // picks from there.  Picks at positions >= 32 (rows of higher degree) are read directly.
     __shared__ i4 stage[kNT / kWave][8][8 + 1];  // +1: rows start in different LDS banks
     const int lane = tid & (kWave - 1), wid = tid / kWave, j = lane >> 3, part = lane & 7;
-    // far picks (position >= kSeg): direct reads, batched; the neighbour id replaces the position as ~id
+    // far picks (position >= kSeg): direct reads, batched; the entry replaces the position in `chosen`, and a bit of
+    // `farmask` (cnt <= 32) says so -- entries may carry a degree tag in their top bits, so their sign means nothing
+    uint32_t farmask = 0u;
     for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
       int32_t nb[8];
       bool far[8];
@@ -727,7 +801,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (far[u]) chosen[k0 + u][tid] = ~nb[u];
+        if (far[u]) {
+          chosen[k0 + u][tid] = (int32_t)((uint32_t)nb[u] & pick_mask);
+          farmask |= 1u << (k0 + u);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -737,9 +814,10 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       if ((lane >> 3) == r) {
         const int32_t* row = reinterpret_cast<const int32_t*>(&stage[wid][lane & 7][0]);
         for (int32_t k = 0; k < cnt; ++k) {
-          // unsampled rows take every position in order; positions past the staged line were fetched above
-          const int32_t c = (smp || k >= kSeg) ? chosen[k][tid] : k;
-          chosen[k][tid] = c >= 0 ? row[c + kSegOff] : ~c;  // now the neighbour id
+          if ((farmask >> k) & 1u) continue;  // fetched above
+          // unsampled rows take every position in order
+          const int32_t c = smp ? chosen[k][tid] : k;
+          chosen[k][tid] = (int32_t)((uint32_t)row[c + kSegOff] & pick_mask);  // now the neighbour entry
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -759,7 +837,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (k0 + u < cnt) G(s.cval)[p0 + k0 + u] = nb[u];
+        if (k0 + u < cnt) G(s.cval)[p0 + k0 + u] = sizeof(ColT) == 4 ? (int32_t)((uint32_t)nb[u] & pick_mask) : nb[u];
     }
   }
 }
@@ -768,7 +846,7 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
 template <typename ColT>
 __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                              const ColT* __restrict__ col, int32_t h, int32_t f,
-                                                             int32_t replace) {
+                                                             int32_t replace, uint32_t idmask) {
   SPP_GROUP_BLOCK(gg);
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const int32_t T = s.st->cnt[h];
@@ -787,14 +865,15 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
   int32_t cnt_, smp_;
   target_counts(deg, f, replace, cnt_, smp_);
   const int32_t w = smp_ ? (int32_t)s.evals[p] : k;
-  s.cval[p] = (int32_t)col[s.rowstart[i] + w];
+  const int32_t c = (int32_t)col[s.rowstart[i] + w];
+  s.cval[p] = sizeof(ColT) == 4 ? (int32_t)((uint32_t)c & idmask) : c;  // (the int32 copy may carry degree tags)
 }
 
 // ----------------------------------------------------------------------------------------------
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                      int32_t cb_log2, int64_t pcap) {
+                                                      int32_t cb_log2, int64_t pcap, uint32_t idmask) {
   SPP_GROUP_BLOCK(gg);
   __shared__ int32_t lh[kMaxBuckets];
   __shared__ int32_t lscan[kTileNT / kWave + 1];
@@ -817,16 +896,11 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
   const int32_t E = err0 ? 0 : E0;
   if (base >= E && bx_ != 0) return;  // tile 0 always takes part (E may be 0)
   const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
-#pragma unroll
-  for (int u = 0; u < kTileEPT; ++u) {
-    const int64_t p = base + u * kTileNT + threadIdx.x;
-    if (p >= E) v[u] = -1;  // node ids are >= 0
-  }
   for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < kTileEPT; ++u)
-    if (v[u] >= 0) atomicAdd(&lh[bucket_of((uint32_t)v[u], cb_log2)], 1);
+  for (int u = 0; u < kTileEPT; ++u)  // (entries may carry a degree tag above the id bits: validity is the position's)
+    if (base + u * kTileNT + threadIdx.x < E) atomicAdd(&lh[bucket_of((uint32_t)v[u] & idmask, cb_log2)], 1);
   __syncthreads();
   for (int b = threadIdx.x; b < nbk; b += kTileNT)
     if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
@@ -861,7 +935,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
 // inv[p] (where edge p went) is stored in position order -- also coalesced -- so that the per-edge
 // results of k_bucket_dedup can stay in bucket order and be fetched back by reads (k_hop_flag).
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                         int32_t h, int32_t cb_log2, int64_t pcap) {
+                                                         int32_t h, int32_t cb_log2, int64_t pcap, uint32_t idmask) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t sc_lds[];
   const int32_t nbk = 1 << cb_log2;
@@ -887,16 +961,17 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     v[u] = cval[p < pcap ? p : pcap - 1];
   }
   if (base >= E || err0) return;
+  bool ok[kScatterEPT];
 #pragma unroll
   for (int u = 0; u < kScatterEPT; ++u) {
-    const int64_t p = base + u * kTileNT + threadIdx.x;
-    if (p >= E) v[u] = -1;
+    ok[u] = base + u * kTileNT + threadIdx.x < E;
+    v[u] = (int32_t)((uint32_t)v[u] & idmask);  // the node id without its degree tag
   }
   for (int b = threadIdx.x; b < nbk; b += kTileNT) cur[b] = 0;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kScatterEPT; ++u)
-    if (v[u] >= 0) atomicAdd(&cur[bucket_of((uint32_t)v[u], cb_log2)], 1);
+    if (ok[u]) atomicAdd(&cur[bucket_of((uint32_t)v[u], cb_log2)], 1);
   __syncthreads();
   // exclusive scan of the tile histogram (first slot of every bucket in the LDS staging order) and
   // one global reservation per non-empty bucket
@@ -924,7 +999,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kScatterEPT; ++u) {
-    if (v[u] < 0) continue;
+    if (!ok[u]) continue;
     const uint32_t c = (uint32_t)v[u];
     const uint32_t b = bucket_of(c, cb_log2);
     const int32_t slot = atomicAdd(&cur[b], 1);  // order inside a bucket is irrelevant (min / max are commutative)
@@ -1220,7 +1295,8 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, ui
 // fast path: one lane per target row.  Local ids of the row's edges (rank lookups for the nodes that
 // are new in this hop), n_ids.push_back for the row's first occurrences (sample_cpu.hpp:50-60), rank
 // sort of the <= 32 ids staged in LDS (sample_cpu.hpp:126).
-__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h) {
+__global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
+                                                   uint32_t idmask, int32_t idbits) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
   int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(rows_lds);
@@ -1255,7 +1331,10 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
       int32_t id = (int32_t)v[u];
       if (v[u] >= (uint32_t)T) {
         id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
-        if (q[u] == (uint32_t)(p0 + k0 + u)) s.n_ids[id] = c[u];  // n_ids.push_back(c) at its first occurrence
+        if (q[u] == (uint32_t)(p0 + k0 + u)) {  // n_ids.push_back(c) at its first occurrence
+          s.n_ids[id] = (int32_t)((uint32_t)c[u] & idmask);
+          if (idbits < 32) s.dtag[id] = (uint8_t)((uint32_t)c[u] >> idbits);  // the node's degree tag travels with it
+        }
       }
       a[k0 + u][tid] = id;
     }
@@ -1704,6 +1783,8 @@ using namespace spp;
 struct Col32 {
   int32_t* p = nullptr;
   int device = 0;
+  int idbits = 32;       // < 32: the entries carry min(degree, cap) above bit idbits (k_narrow_col_tagged)
+  uint32_t cap = 0;
   ~Col32() {
     if (p) {
       (void)hipSetDevice(device);
@@ -1718,11 +1799,10 @@ static std::map<std::tuple<const void*, int64_t, int>, std::weak_ptr<Col32>> g_c
 struct RowStubs {
   stub4* p = nullptr;
   int device = 0;
+  bool from_col32 = false;  // copied from the int32 neighbour array (tagged entries, if that array is tagged)
   ~RowStubs() {
-    if (p) {
-      (void)hipSetDevice(device);
-      (void)hipFree(p);
-    }
+    (void)hipSetDevice(device);
+    if (p) (void)hipFree(p);
   }
 };
 static std::map<std::tuple<const void*, const void*, int64_t, int>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
@@ -1768,6 +1848,10 @@ struct spp_sampler {
   int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
   std::shared_ptr<RowStubs> stubs_owner;
   const stub4* stubs = nullptr;      // = stubs_owner->p (NULL: degree from rowptr, neighbours from the array only)
+  int idbits = 32;                   // bits of a node id inside an entry of col32 / the stubs (32: untagged)
+  uint32_t idmask = 0xffffffffu;     // mask of those bits
+  uint32_t tag_cap = 0;              // largest degree a tag holds (0: this sampler does not use the tags)
+  bool use_tags = false;             // degree pass of hops >= 1 from the nodes' tags, k_hop_pick takes headers from the stubs
   // epoch arena of mt19937 streams (sampler_rng_arena): one stream per batch of the current range table
   uint32_t* rng_arena = nullptr;
   int64_t rng_arena_words = 0;       // allocated size
@@ -1930,6 +2014,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     ptr = static_cast<type*>(v_);                                                        \
   }
     A(p.n_ids, int32_t, ucap);
+    A(p.dtag, uint8_t, ucap + 16);
     A(p.deg, int32_t, tmax);
     A(p.rowstart, int64_t, tmax);
     A(p.rng[0], uint32_t, s->dcap + kMtSlack);
@@ -1995,17 +2080,36 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
           set_error("spp_sampler_create: hipMalloc of the int32 neighbour array failed");
           rc = SPP_ERR_HIP;
         } else {
-          hipLaunchKernelGGL(k_narrow_col, dim3(256 * 16), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, c->p);
+          // degree tags in the spare top bits (SPP_DEG_TAGS=0: plain ids), when at least 3 bits are spare
+          int idbits = 1;
+          while (idbits < 32 && ((int64_t)1 << idbits) < cfg->num_nodes) ++idbits;
+          const char* et = getenv("SPP_DEG_TAGS");
+          uint8_t* deg8 = nullptr;
+          if ((!et || atoi(et) != 0) && idbits <= 29 &&
+              hipMalloc((void**)&deg8, (size_t)cfg->num_nodes) == hipSuccess) {
+            const int tagbits = std::min(32 - idbits, 8);
+            c->idbits = idbits;
+            c->cap = (1u << tagbits) - 1u;
+            hipLaunchKernelGGL(k_build_deg8, dim3(256 * 16), dim3(256), 0, nullptr, cfg->rowptr_dev, cfg->num_nodes, deg8);
+            hipLaunchKernelGGL(k_narrow_col_tagged, dim3(256 * 32), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, deg8,
+                               idbits, c->cap, c->p);
+          } else {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(k_narrow_col, dim3(256 * 16), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, c->p);
+          }
           if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             set_error("spp_sampler_create: narrowing the neighbour array failed");
             rc = SPP_ERR_HIP;
           }
+          if (deg8) (void)hipFree(deg8);
         }
         if (rc == SPP_OK) g_col32[key] = c;
       }
       if (rc == SPP_OK) {
         s->col32_owner = c;
         s->col32 = c->p;
+        s->idbits = c->idbits;
+        s->idmask = c->idbits < 32 ? ((1u << c->idbits) - 1u) : 0xffffffffu;
         s->bytes += (int64_t)sizeof(int32_t) * cfg->nnz;
       }
     }
@@ -2038,6 +2142,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
           else
             hipLaunchKernelGGL(k_build_stubs<int64_t>, dim3(grid), dim3(256), 0, nullptr, cfg->rowptr_dev, cfg->col_dev,
                                cfg->num_nodes, c->p);
+          c->from_col32 = s->col32 != nullptr;
           if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
             set_error("spp_sampler_create: building the row stubs failed");
             rc = SPP_ERR_HIP;
@@ -2051,6 +2156,14 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       s->stubs_owner = c;
       s->stubs = c->p;
       s->bytes += (int64_t)need;
+      // Degree tags are used when the stubs were copied from the tagged int32 array and every later hop's fanout is
+      // below the tags' cap (then min(degree, cap) decides "all neighbours or f picks" exactly)
+      bool fits = s->col32 && c->from_col32 && s->idbits < 32 && !cfg->replace;
+      for (int h = 1; h < H && fits; ++h) fits = cfg->sizes[h] >= 0 && (uint64_t)cfg->sizes[h] < s->col32_owner->cap;
+      if (fits) {
+        s->use_tags = true;
+        s->tag_cap = s->col32_owner->cap;
+      }
     }
   }
   if (rc == SPP_OK) {
@@ -2328,7 +2441,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
   ga.grid = GG(gseed);
   hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom, rowptr, stubs,
-                     (int32_t)s->cfg.sizes[0], replace);  // includes hop 0's degree pass
+                     (int32_t)s->cfg.sizes[0], replace, s->tag_cap);  // includes hop 0's degree pass
+  const uint32_t idmask = s->idmask;
+  const uint32_t pick_mask = s->use_tags ? 0xffffffffu : idmask;
+  const int32_t row_idbits = s->use_tags ? s->idbits : 32;
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
@@ -2336,7 +2452,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
     for (int rep = 0; h > 0 && rep < dup.count; ++rep) {
       const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
-      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, h, f, replace, (int32_t)s->tcap[h]);
+      hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, s->use_tags ? 1 : 0, h, f, replace, (int32_t)s->tcap[h]);
     }
     // generic hops are sized after a host sync, so the device-side edge-capacity check is disabled
     const int32_t ecap_dev =
@@ -2348,22 +2464,25 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     unsigned ge;
     for (int rep = 0; !s->generic[h] && rep < dup.pick - 1; ++rep)
-      if (col32 && stubs)
-        hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+      if (col32 && stubs && s->use_tags)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t, true, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
     if (!s->generic[h]) {
-      if (col32 && stubs)
+      if (col32 && stubs && s->use_tags)
+        hipLaunchKernelGGL((k_hop_pick<false, int32_t, true, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
+      else if (col32 && stubs)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
       else if (col32)
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+                           col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
       else if (stubs)
         hipLaunchKernelGGL((k_hop_pick<false, int64_t, true>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
       else
         hipLaunchKernelGGL((k_hop_pick<false, int64_t, false>), dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt),
-                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+                           col, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
       ge = (unsigned)std::max<int64_t>(1, ceil_div(s->ecap[h], kNT));
     } else {
       // slow path (n == 1): the edge count is needed on the host to size launches and scratch
@@ -2374,13 +2493,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       SPP_TRY(grow_edge_scratch(s, first_slot, h, E, st));
       ge = (unsigned)std::max<int64_t>(1, ceil_div(E, kNT));
       hipLaunchKernelGGL((k_hop_pick<true, int64_t, false>), dim3((gt) * gy), dim3(kNT), sizeof(int32_t) * kNT, st, s->d_slots,
-                         GG(gt), col, stubs, h, f, replace, 0, ecap_dev, s->dcap, (int32_t)s->tcap[h]);
+                         GG(gt), col, stubs, h, f, replace, 0, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask);
       if (col32)
         hipLaunchKernelGGL(k_hop_expand_generic<int32_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col32,
-                           h, f, replace);
+                           h, f, replace, idmask);
       else
         hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col,
-                           h, f, replace);
+                           h, f, replace, idmask);
     }
     // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
@@ -2392,8 +2511,8 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
     for (int rep = 0; rep < dup.tiles; ++rep) {  // (the histogram resets the cursors the scatter advanced: the pair is idempotent)
-      hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap);
-      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap);
+      hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap, idmask);
+      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap, idmask);
     }
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
@@ -2409,7 +2528,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
                          (int32_t)s->tcap[H], pcap);
     if (!s->generic[h]) {
       for (int rep = 0; rep < dup.rows; ++rep)
-        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h);
+        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];

@@ -38,6 +38,9 @@ _MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "32"))
 # distributed Sessions pipeline three stages (sample -> exchange -> consume), one slot-set each plus
 # one in hand: 4 sets of 8
 _MAX_SLOTS_DIST = int(os.environ.get("SPP_MAX_SLOTS_DIST", "32"))
+# group delivery: groups kept delivered ahead of the one being handed out (their slot-sets go back to the sampler
+# that much earlier; each holds ~2.2 GB of outputs at papers scale)
+_LOOKAHEAD_GROUPS = max(1, int(os.environ.get("SPP_LOOKAHEAD_GROUPS", "1")))
 
 
 # --------------------------------------------------------------------------------------------
@@ -922,7 +925,7 @@ class Session:
         if cur != stream:                              # delivered on another stream than the caller is on now
             cur.wait_event(ev)
         G = self.group_size
-        if len(self._ready) < G and not self._ended:
+        if len(self._ready) < _LOOKAHEAD_GROUPS * G and not self._ended:
             # consumer-issued exchanges: always at this program point, blocking (every rank issues the same
             # sequence of collectives); otherwise opportunistic
             self._fetch_group(self._consumer_issue)

@@ -7,7 +7,10 @@ of a short epoch with the oracle:
   * SPP_ROW_STUBS=0      -- no row stubs: degrees from rowptr, cooperative reads of the int32 neighbour array;
   * both off             -- lane-private reads of the int64 array;
   * SPP_GROUP_SIZE=3     -- ragged groups, slot-sets of 3;
-  * SPP_DEDUP_BUCKET=64  -- many small dedup buckets (coarse/fine bucket runs, 2^11-slot LDS tables)."""
+  * SPP_DEDUP_BUCKET=64  -- many small dedup buckets (coarse/fine bucket runs, 2^11-slot LDS tables);
+  * SPP_DEG_TAGS=0       -- plain neighbour ids: the degree pass of hops >= 1 reads the stub headers instead of the tags the nodes bring along;
+  * SPP_GROUP_DELIVERY=0 -- one delivery launch per batch instead of one per group;
+  * SPP_WHATIF_DUP=...   -- the measurement aid that launches the idempotent kernels twice changes nothing."""
 import os
 import subprocess
 import sys
@@ -62,6 +65,10 @@ print("CHILD_OK", n)
     {"SPP_ROW_STUBS": "0", "SPP_COL32": "0"},
     {"SPP_GROUP_SIZE": "3"},
     {"SPP_DEDUP_BUCKET": "64"},
+    {"SPP_DEG_TAGS": "0"},
+    {"SPP_DEG_TAGS": "1", "SPP_GROUP_SIZE": "2", "SPP_DEDUP_BUCKET": "64"},
+    {"SPP_GROUP_DELIVERY": "0"},
+    {"SPP_WHATIF_DUP": "count,pick,tiles,flag,rows"},
     {"SPP_RNG_ARENA_MB": "0", "SPP_GROUP_SIZE": "5", "SPP_XCD_AFFINITY": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_chain_paths_are_bit_exact(env):
