@@ -1184,10 +1184,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
 // ----------------------------------------------------------------------------------------------
 constexpr int kFlagNT = kNT;                    // 256 threads: a 1024-thread workgroup needs 16 free wave slots on ONE CU at
                                                 // once and waited for them behind the delivery kernel (36 us per batch in situ, 12 alone)
-#ifndef SPP_FLAG_ROUNDS
-#define SPP_FLAG_ROUNDS 4
-#endif
-constexpr int kFlagRounds = SPP_FLAG_ROUNDS;    // positions per thread; one round = one 256-position block = 4 bitmap words
+constexpr int kFlagRounds = 4;                  // positions per thread; one round = one 256-position block = 4 bitmap words
 constexpr int kFlagSpan = kFlagNT * kFlagRounds;  // positions per workgroup (one ticket each)
 static_assert(kFlagNT == 256, "a round of the workgroup is one rank block");
 
@@ -1299,49 +1296,34 @@ __device__ __forceinline__ int32_t local_id_of(const SlotPtrs& s, uint32_t T, ui
 // are new in this hop), n_ids.push_back for the row's first occurrences (sample_cpu.hpp:50-60), rank
 // sort of the <= 32 ids staged in LDS (sample_cpu.hpp:126).
 __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                   uint32_t idmask, int32_t idbits, int32_t tcap, int64_t pcap) {
+                                                   uint32_t idmask, int32_t idbits) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t rows_lds[];  // [f][kNT]: the row's local ids, one column per lane (dynamic LDS)
   int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(rows_lds);
   const SlotPtrs& s = slots[gg.first_slot + by_];
-  const SPP_GLOBAL SlotState* st = G(s.st);
-  const SPP_GLOBAL int32_t* rp = G(s.out_rowptr[h]);
-  const SPP_GLOBAL uint32_t* evals = G(s.evals);
-  const SPP_GLOBAL int32_t* cval = G(s.cval);
-  const SPP_GLOBAL RankWord* fwords = G(s.fwords);
-  const SPP_GLOBAL int32_t* fsum = G(s.fsum);
-  SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
-  SPP_GLOBAL uint8_t* dtag = G(s.dtag);
+  const int32_t T = s.st->cnt[h];
   const int32_t i = bx_ * kNT + threadIdx.x;
-  // ---- round trip 1: state words and the row's bounds together (index clamped: T is not known yet; the row
-  // pointer array holds tcap + 1 entries)
-  const int32_t ic = i < tcap ? i : tcap - 1;
-  const int32_t T = st->cnt[h];
-  const int32_t err0 = st->error;
-  const int32_t p0 = rp[ic];
-  const int32_t p1 = rp[ic + 1];
-  if (i >= T || err0) return;
+  if (i >= T || s.st->error) return;
   const int tid = threadIdx.x;
-  const int32_t n = p1 - p0;
-  // 8 edges at a time; each round's loads are all issued before any of them is used (clamped indices, not
-  // predicated loads: a predicate makes the compiler wait for each load before it issues the next)
+  const int32_t p0 = s.out_rowptr[h][i];
+  const int32_t n = s.out_rowptr[h][i + 1] - p0;
+  // 8 edges at a time; each round's loads are all issued before any of them is used
   for (int32_t k0 = 0; k0 < n; k0 += 8) {
     uint32_t v[8], q[8];
     int32_t c[8], fs[8];
     RankWord rw[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // ---- round trip 2: table values and neighbour entries of the row
-      const int64_t p = (k0 + u < n) ? (int64_t)p0 + k0 + u : (int64_t)p0;
-      const int64_t pc = p < pcap ? p : pcap - 1;
-      v[u] = evals[pc];
-      c[u] = cval[pc];
+    for (int u = 0; u < 8; ++u) {
+      const bool on = k0 + u < n;
+      v[u] = on ? s.evals[p0 + k0 + u] : 0u;
+      c[u] = on ? s.cval[p0 + k0 + u] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // ---- round trip 3: rank records of the nodes that are new in this hop (others: record 0)
+    for (int u = 0; u < 8; ++u) {
       const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
       q[u] = fresh ? v[u] - (uint32_t)T : 0u;
-      fs[u] = fsum[q[u] >> 8];
-      rw[u] = load_rank_word(fwords, q[u] >> 6);
+      fs[u] = fresh ? s.fsum[q[u] >> 8] : 0;
+      rw[u] = fresh ? s.fwords[q[u] >> 6] : RankWord{0ull, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1350,14 +1332,14 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
       if (v[u] >= (uint32_t)T) {
         id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
         if (q[u] == (uint32_t)(p0 + k0 + u)) {  // n_ids.push_back(c) at its first occurrence
-          n_ids[id] = (int32_t)((uint32_t)c[u] & idmask);
-          if (idbits < 32) dtag[id] = (uint8_t)((uint32_t)c[u] >> idbits);  // the node's degree tag travels with it
+          s.n_ids[id] = (int32_t)((uint32_t)c[u] & idmask);
+          if (idbits < 32) s.dtag[id] = (uint8_t)((uint32_t)c[u] >> idbits);  // the node's degree tag travels with it
         }
       }
       a[k0 + u][tid] = id;
     }
   }
-  SPP_GLOBAL int32_t* out = G(s.out_col[h]) + p0;
+  int32_t* out = s.out_col[h] + p0;
   for (int32_t k = 0; k < n; ++k) {
     const int32_t v = a[k][tid];
     int32_t rank = 0;
@@ -2546,8 +2528,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
                          (int32_t)s->tcap[H], pcap);
     if (!s->generic[h]) {
       for (int rep = 0; rep < dup.rows; ++rep)
-        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits,
-                           (int32_t)s->tcap[h], pcap);
+        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits);
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];

@@ -40,7 +40,7 @@ _MAX_SLOTS = int(os.environ.get("SPP_MAX_SLOTS", "32"))
 _MAX_SLOTS_DIST = int(os.environ.get("SPP_MAX_SLOTS_DIST", "32"))
 # group delivery: groups kept delivered ahead of the one being handed out (their slot-sets go back to the sampler
 # that much earlier; each holds ~2.2 GB of outputs at papers scale)
-_LOOKAHEAD_GROUPS = max(1, int(os.environ.get("SPP_LOOKAHEAD_GROUPS", "1")))
+_LOOKAHEAD_GROUPS = max(1, int(os.environ.get("SPP_LOOKAHEAD_GROUPS", "2")))
 
 
 # --------------------------------------------------------------------------------------------
@@ -574,7 +574,6 @@ class Session:
         self._ready = collections.deque()          # (record, ready event, delivery stream) of delivered batches
         self._ended = False
         self.last_ready_event = None               # event after which the batch handed out last is complete
-        self._consumer_issue = bool(self.native_exchange and self._xc.issue_on_consumer)
         self._consumer_stream = None
         self._e_id = torch.empty(0, dtype=torch.int64, device=self._dev)
         # (src pointer, rows, row bytes) of the resident feature / label matrices, built once
@@ -926,9 +925,12 @@ class Session:
             cur.wait_event(ev)
         G = self.group_size
         if len(self._ready) < _LOOKAHEAD_GROUPS * G and not self._ended:
-            # consumer-issued exchanges: always at this program point, blocking (every rank issues the same
-            # sequence of collectives); otherwise opportunistic
-            self._fetch_group(self._consumer_issue)
+            # With the native exchange the look-ahead is taken at THIS program point on every rank, blocking: how
+            # many groups a rank has exported decides which chains and exchanges its session threads may issue,
+            # and a rank that ran ahead of its peers opportunistically would sit in a collective (or in quiesce())
+            # that the others only join after a barrier it never reaches.  Consumer-issued exchanges are issued
+            # here.  Single-GPU sessions look ahead opportunistically.
+            self._fetch_group(self.native_exchange)
         if self._ended and not self._ready:
             self._finish()
         return rec

@@ -41,12 +41,20 @@ for strategy in ("vip", "degree-desc"):
         skip_nonfull_batch=False, pin_memory=False, distributed=True, partition_book=pb, cache=cache,
         force_exact_num_batches=True, exact_num_batches=16, count_remote_frequency=False, use_cache=True)
     tot = loc = hit = 0
+    remote = []                  # per batch: the ids to fetch (all peers)
     for proto in iter(FastSampler(2, 16, cfg)):
         counts = [int(t.numel()) for t in proto.partition_nids]
         tot += sum(counts) + int(proto.cached_nids.numel())
         loc += counts[rank]
         hit += int(proto.cached_nids.numel())
+        remote.append(torch.cat([t for m, t in enumerate(proto.partition_nids) if m != rank]))
     fetch = tot - loc - hit
+    # rows requested more than once inside a group of 8 batches (what a per-group request list would save)
+    dup = []
+    for g0 in range(0, len(remote), 8):
+        grp = torch.cat(remote[g0:g0 + 8])
+        dup.append(1.0 - torch.unique(grp).numel() / max(1, grp.numel()))
+    print(f"  duplicate requests inside a group of 8 batches: {sum(dup) / len(dup):.1%} of the rows to fetch", flush=True)
     print(f"{name} P={P} {'federated' if federated else 'global'} seeds, cache {frac:.0%} ({cv.numel()} rows, {strategy}): per batch {tot/16:.0f} nodes = "
           f"{loc/tot:.1%} local + {hit/tot:.1%} cache hits + {fetch/tot:.1%} to fetch "
           f"({fetch/16*F*2/1e6:.0f} MB of rows per batch)", flush=True)

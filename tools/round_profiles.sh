@@ -18,8 +18,9 @@ f=$(find "$out" -name "${tag}_bench_papers_kernel_trace.csv" | head -1)
 python3 tools/trace_report.py "$f" 192 > "$out/${tag}_pipeline_trace_report.txt"
 rm -f "$f" "$out"/${tag}_bench_papers_agent_info.csv "$out"/${tag}_bench_papers_domain_stats.csv
 (head -1 "$out/${tag}_bench_papers_kernel_stats.csv"; grep "spp::" "$out/${tag}_bench_papers_kernel_stats.csv") > "$out/k.tmp" && mv "$out/k.tmp" "$out/${tag}_bench_papers_kernel_stats.csv"
-# PMC: pipeline traffic per kernel
+# PMC: pipeline traffic per kernel (single-GPU path, then the partitioned path at world size 1)
 tools/pmc_pipeline.sh "$out" "${tag}_pipeline_pmc" > /dev/null || exit 1
+EXTRA_ARGS="--gpus 1 --force-distributed" tools/pmc_pipeline.sh "$out" "${tag}_partitioned_pmc" > /dev/null || exit 1
 # PMC: the row gather in isolation, papers shape, with its calibration launch
 for c in FETCH_SIZE WRITE_SIZE; do
   F=128 STRIDE=256 TABLE_ROWS=111059956 ROWS=947000 timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d "$out" -o "g_$c" -- python3 tools/pmc_gather.py > /dev/null 2>> "$out/bench.err" || exit 1

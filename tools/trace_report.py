@@ -1,8 +1,8 @@
 """Steady-state timeline report from a rocprofv3 --kernel-trace CSV of bench.py.
 
-usage: trace_report.py <kernel_trace.csv> [n_last_batches=128]
+usage: trace_report.py <kernel_trace.csv> [n_last_batches=128] [batches per group = 8]
 
-Window = the last n k_deliver launches.  Prints, for the spp:: kernels inside it: per kernel (and per
+Window = the delivery launches of the last n batches (a k_deliver_group launch delivers a whole group).  Prints, for the spp:: kernels inside it: per kernel (and per
 grid size, which tells the hops apart) calls / total / average duration; per-batch kernel time of the
 delivery kernel and of the sampling chain; the time at least one kernel was running (union), the sum
 of kernel time, the average concurrency and the window per batch."""
@@ -22,17 +22,20 @@ for r in csv.DictReader(open(path)):
                  int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), r["Queue_Id"]))
 rows.sort()
 deliver = [x for x in rows if x[2].startswith("k_deliver")]
+per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 8     # batches per sampling / delivery group
 if not deliver:
     # sampling only (tools/microbench.py chain): the window is the last n batches' worth of k_seed_init launches
     seeds = [x for x in rows if x[2].startswith("k_seed_init")]
-    per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 8     # batches per launch (group size)
     k = max(1, min(len(seeds) - 1, nlast // per_launch))
     lo, hi = seeds[-k - 1][0], seeds[-1][0]
     nlast = k * per_launch
 else:
-    if len(deliver) < nlast:
-        nlast = len(deliver)
-    lo, hi = deliver[-nlast][0], deliver[-1][1]
+    got, first = 0, len(deliver)
+    while first > 0 and got < nlast:
+        first -= 1
+        got += per_launch if deliver[first][2].startswith("k_deliver_group") else 1
+    nlast = got
+    lo, hi = deliver[first][0], deliver[-1][1]
 win = [x for x in rows if x[0] >= lo and x[1] <= hi]
 tot = collections.defaultdict(lambda: [0, 0])
 for s, e, n, gx, gy, q in win:
