@@ -528,6 +528,21 @@ spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, const int64_t* 
                                       const float* grad_z_dev, float* grad_x_dev, float* grad_a_src_dev,
                                       float* grad_a_dst_dev, void* stream);
 
+/* spp_gat_aggregate_backward with the input gradient by GATHER over the transposed hop (built on the fly: count,
+ * scan, fill) instead of E x K fp32 atomics: grad_x_dev [S, K] fp32 is written COMPLETELY, including the rank-1
+ * terms of the logits -- grad_a_src[s] v_src for every source and grad_a_dst[s] v_dst for the first T -- that
+ * the atomic form leaves to the caller (a_src = x v_src, a_dst = x[:T] v_dst).  grad_a_src_dev [S] is zeroed by the
+ * caller as before.  workspace_dev: spp_gat_aggregate_backward_gather_workspace_bytes(T, S, E) bytes, 16-byte aligned. */
+int64_t spp_gat_aggregate_backward_gather_workspace_bytes(int64_t num_targets, int64_t num_sources, int64_t num_edges);
+spp_status spp_gat_aggregate_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                             int64_t num_sources, int64_t num_edges, const void* x_dev,
+                                             int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                             const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                             const float* z_dev, const float* row_max_dev, const float* row_sum_dev,
+                                             const float* grad_z_dev, const float* v_src_dev, const float* v_dst_dev,
+                                             float* grad_x_dev, float* grad_a_src_dev, float* grad_a_dst_dev,
+                                             void* workspace_dev, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

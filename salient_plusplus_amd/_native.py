@@ -131,6 +131,9 @@ SIGNATURES = {
     "spp_gat_aggregate_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p]),
     "spp_gat_aggregate_backward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
     "spp_gat_backward": (C.c_int, [p, p, i64, p, i64, p, p, C.c_float, p, p, p, p, p, p, p, p]),
+    "spp_gat_aggregate_backward_gather_workspace_bytes": (i64, [i64, i64, i64]),
+    "spp_gat_aggregate_backward_gather": (C.c_int, [p, p, i64, i64, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p,
+                                                    p, p, p, p, p, p, i64, p]),
     "spp_session_try_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
     "spp_session_quiesce": (C.c_int, [p]),
     "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),

@@ -811,7 +811,10 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
                                                         float slope, const float* __restrict__ z,
                                                         const float* __restrict__ row_max, const float* __restrict__ row_sum,
                                                         const float* __restrict__ g, int lpt_log2, float* __restrict__ grad_x,
-                                                        float* __restrict__ grad_a_src, float* __restrict__ grad_a_dst) {
+                                                        float* __restrict__ grad_a_src, float* __restrict__ grad_a_dst,
+                                                        float* __restrict__ alpha_e, float* __restrict__ alpha_self) {
+  // alpha_e / alpha_self (optional): the attention weight of every CSR entry (0 for a dropped diagonal entry) and of
+  // every target's self loop -- what the input gradient by GATHER over the transposed hop needs (k_gat_gx_gather)
   // lpt = min(64, K rounded up to a power of two) lanes per target
   const int lpt = 1 << lpt_log2;
   const int lane = threadIdx.x & (lpt - 1);
@@ -869,6 +872,10 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
       }
     }
     gh = group_sum(gh);
+    if (alpha_e && on && lane == 0) {
+      if (k < b) alpha_self[t] = a;
+      else alpha_e[k] = a;  // (a == 0 for a dropped diagonal entry)
+    }
     if (use) {
       const float ge = a * (gh - go) * (raw > 0.f ? 1.f : slope);
       gad += ge;
@@ -876,6 +883,69 @@ __global__ __launch_bounds__(kAggNT) void k_gat_agg_bwd(const int64_t* __restric
     }
   }
   if (live && lane == 0) grad_a_dst[t] = gad;
+}
+
+// transposed hop with the CSR entry of every (source, target) pair kept: tedge[pos] = k, ttgt[pos] = t
+__global__ __launch_bounds__(kAggNT) void k_tr_fill_e(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                      int64_t T, const int32_t* __restrict__ start,
+                                                      int32_t* __restrict__ cursor, int32_t* __restrict__ ttgt,
+                                                      int32_t* __restrict__ tedge) {
+  const int64_t t = (int64_t)blockIdx.x * kAggNT + threadIdx.x;
+  if (t >= T) return;
+  const int64_t b = rowptr[t], e = rowptr[t + 1];
+  for (int64_t k = b; k < e; ++k) {
+    const int64_t s = col[k];
+    const int32_t pos = start[s] + atomicAdd(&cursor[s], 1);
+    ttgt[pos] = (int32_t)t;
+    tedge[pos] = (int32_t)k;
+  }
+}
+
+// Input gradient of the aggregate-then-project GAT layer by GATHER (no fp32 atomics, no zero fill, no separate rank-1
+// passes):  grad_x[s,:] = sum over the targets t of s: alpha_ts grad_z[t,:]  (+ the self loop's alpha_ss grad_z[s,:], s < T)
+//                         + grad_a_src[s] v_src  (+ grad_a_dst[s] v_dst, s < T)        -- a_src = x v_src, a_dst = x[:T] v_dst
+__global__ __launch_bounds__(kAggNT) void k_gat_gx_gather(const int32_t* __restrict__ start, const int32_t* __restrict__ ttgt,
+                                                          const int32_t* __restrict__ tedge, const float* __restrict__ alpha_e,
+                                                          const float* __restrict__ alpha_self, int64_t T, int64_t S,
+                                                          const float* __restrict__ g, int64_t K, int lpr_log2,
+                                                          const float* __restrict__ grad_a_src,
+                                                          const float* __restrict__ grad_a_dst,
+                                                          const float* __restrict__ v_src, const float* __restrict__ v_dst,
+                                                          float* __restrict__ grad_x) {
+  const int lpr = 1 << lpr_log2;
+  const int lane = threadIdx.x & (lpr - 1);
+  const int64_t srow = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
+  if (srow >= S) return;
+  const int32_t b = start[srow], e = start[srow + 1];
+  const float gas = grad_a_src[srow];
+  const float gad = srow < T ? grad_a_dst[srow] : 0.f;
+  const float aself = srow < T ? alpha_self[srow] : 0.f;
+  for (int64_t c = (int64_t)lane * 4; c < K; c += (int64_t)lpr * 4) {
+    const float4 vs = *reinterpret_cast<const float4*>(v_src + c);
+    float4 acc = make_float4(gas * vs.x, gas * vs.y, gas * vs.z, gas * vs.w);
+    if (srow < T) {
+      const float4 vd = *reinterpret_cast<const float4*>(v_dst + c);
+      const float4 gs = *reinterpret_cast<const float4*>(g + srow * K + c);
+      acc.x += gad * vd.x + aself * gs.x; acc.y += gad * vd.y + aself * gs.y;
+      acc.z += gad * vd.z + aself * gs.z; acc.w += gad * vd.w + aself * gs.w;
+    }
+    int32_t k = b;
+    for (; k + 1 < e; k += 2) {  // two independent rows in flight
+      const int32_t t0 = ttgt[k], t1 = ttgt[k + 1];
+      const float w0 = alpha_e[tedge[k]], w1 = alpha_e[tedge[k + 1]];
+      const float4 v0 = *reinterpret_cast<const float4*>(g + (int64_t)t0 * K + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(g + (int64_t)t1 * K + c);
+      acc.x += v0.x * w0 + v1.x * w1; acc.y += v0.y * w0 + v1.y * w1;
+      acc.z += v0.z * w0 + v1.z * w1; acc.w += v0.w * w0 + v1.w * w1;
+    }
+    if (k < e) {
+      const int32_t t0 = ttgt[k];
+      const float w0 = alpha_e[tedge[k]];
+      const float4 v0 = *reinterpret_cast<const float4*>(g + (int64_t)t0 * K + c);
+      acc.x += v0.x * w0; acc.y += v0.y * w0; acc.z += v0.z * w0; acc.w += v0.w * w0;
+    }
+    *reinterpret_cast<float4*>(grad_x + srow * K + c) = acc;
+  }
 }
 
 }  // namespace spp
@@ -960,6 +1030,13 @@ extern "C" spp_status spp_gat_aggregate_forward(const int64_t* rowptr_dev, const
   return SPP_OK;
 }
 
+static spp_status gat_aggregate_backward_launch(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                                const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                                const float* z_dev, const float* row_max_dev, const float* row_sum_dev,
+                                                const float* grad_z_dev, float* grad_x_dev, float* grad_a_src_dev,
+                                                float* grad_a_dst_dev, float* alpha_e, float* alpha_self, void* stream);
+
 extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                                  const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
                                                  const float* a_src_dev, const float* a_dst_dev, float negative_slope,
@@ -972,6 +1049,17 @@ extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, cons
   SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev &&
                   grad_a_src_dev && grad_a_dst_dev && reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(z_dev) % 16 == 0, "spp_gat_aggregate_backward: NULL or unaligned buffer");
+  return gat_aggregate_backward_launch(rowptr_dev, col_dev, num_targets, x_dev, x_is_half, x_stride_elems, K, a_src_dev,
+                                       a_dst_dev, negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, grad_x_dev,
+                                       grad_a_src_dev, grad_a_dst_dev, nullptr, nullptr, stream);
+}
+
+static spp_status gat_aggregate_backward_launch(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t K,
+                                                const float* a_src_dev, const float* a_dst_dev, float negative_slope,
+                                                const float* z_dev, const float* row_max_dev, const float* row_sum_dev,
+                                                const float* grad_z_dev, float* grad_x_dev, float* grad_a_src_dev,
+                                                float* grad_a_dst_dev, float* alpha_e, float* alpha_self, void* stream) {
   const bool vec = grad_x_dev == nullptr;
   const int lpt_log2 = lanes_log2(vec ? K / 4 : K);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpt_log2, kAggNT);
@@ -979,13 +1067,91 @@ extern "C" spp_status spp_gat_aggregate_backward(const int64_t* rowptr_dev, cons
   hipLaunchKernelGGL((k_gat_agg_bwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev, col_dev,       \
                      num_targets, static_cast<const TIN*>(x_dev), x_stride_elems, K, a_src_dev, a_dst_dev,            \
                      negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, lpt_log2, grad_x_dev, grad_a_src_dev, \
-                     grad_a_dst_dev)
+                     grad_a_dst_dev, alpha_e, alpha_self)
   if (x_is_half) {
     if (vec) SPP_GAT_BWD(__half, true); else SPP_GAT_BWD(__half, false);
   } else {
     if (vec) SPP_GAT_BWD(float, true); else SPP_GAT_BWD(float, false);
   }
 #undef SPP_GAT_BWD
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" int64_t spp_gat_aggregate_backward_gather_workspace_bytes(int64_t num_targets, int64_t num_sources,
+                                                                     int64_t num_edges) {
+  size_t scan_tmp = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                         (int)(num_sources + 1));
+  // cnt/cursor [S+1] | start [S+1] | ttgt [E] | tedge [E] | alpha_e [E] | alpha_self [T] | inv [T] (k_tr_count's by-product)
+  // | scan temporaries   (each 16-byte aligned)
+  auto up = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+  return up(4 * (num_sources + 1)) * 2 + 3 * up(4 * num_edges) + 2 * up(4 * num_targets) + up((int64_t)scan_tmp) + 64;
+}
+
+// spp_gat_aggregate_backward with the input gradient by GATHER over the transposed hop: grad_x [S, K] is written
+// completely, including the rank-1 terms of the logits (grad_a_src[s] v_src, grad_a_dst[s] v_dst for s < T) that
+// the atomic form leaves to the caller.  grad_a_src_dev [S] is zeroed by the caller as before.
+extern "C" spp_status spp_gat_aggregate_backward_gather(const int64_t* rowptr_dev, const int64_t* col_dev,
+                                                        int64_t num_targets, int64_t num_sources, int64_t num_edges,
+                                                        const void* x_dev, int32_t x_is_half, int64_t x_stride_elems,
+                                                        int64_t K, const float* a_src_dev, const float* a_dst_dev,
+                                                        float negative_slope, const float* z_dev,
+                                                        const float* row_max_dev, const float* row_sum_dev,
+                                                        const float* grad_z_dev, const float* v_src_dev,
+                                                        const float* v_dst_dev, float* grad_x_dev, float* grad_a_src_dev,
+                                                        float* grad_a_dst_dev, void* workspace_dev, int64_t workspace_bytes,
+                                                        void* stream) {
+  SPP_REQUIRE(num_targets >= 0 && num_sources >= num_targets && num_edges >= 0,
+              "spp_gat_aggregate_backward_gather: bad sizes");
+  if (num_sources == 0) return SPP_OK;
+  SPP_TRY(gat_check(K, x_dev, x_stride_elems, x_is_half, "spp_gat_aggregate_backward_gather"));
+  SPP_REQUIRE(num_sources < (1ll << 31) && num_edges < (1ll << 31), "spp_gat_aggregate_backward_gather: 32-bit indices");
+  SPP_REQUIRE(rowptr_dev && a_src_dev && a_dst_dev && z_dev && row_max_dev && row_sum_dev && grad_z_dev && v_src_dev &&
+                  v_dst_dev && grad_x_dev && grad_a_src_dev && grad_a_dst_dev && workspace_dev,
+              "spp_gat_aggregate_backward_gather: NULL buffer");
+  SPP_REQUIRE(reinterpret_cast<uintptr_t>(grad_z_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(z_dev) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(grad_x_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(v_src_dev) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(v_dst_dev) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace_dev) % 16 == 0,
+              "spp_gat_aggregate_backward_gather: buffers must be 16-byte aligned");
+  SPP_REQUIRE(workspace_bytes >= spp_gat_aggregate_backward_gather_workspace_bytes(num_targets, num_sources, num_edges),
+              "spp_gat_aggregate_backward_gather: workspace too small");
+  hipStream_t st = as_stream(stream);
+  auto up = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+  char* w = static_cast<char*>(workspace_dev);
+  int32_t* cnt = reinterpret_cast<int32_t*>(w);
+  w += up(4 * (num_sources + 1));
+  int32_t* start = reinterpret_cast<int32_t*>(w);
+  w += up(4 * (num_sources + 1));
+  int32_t* ttgt = reinterpret_cast<int32_t*>(w);
+  w += up(4 * num_edges);
+  int32_t* tedge = reinterpret_cast<int32_t*>(w);
+  w += up(4 * num_edges);
+  float* alpha_e = reinterpret_cast<float*>(w);
+  w += up(4 * num_edges);
+  float* alpha_self = reinterpret_cast<float*>(w);
+  w += up(4 * num_targets);
+  float* inv = reinterpret_cast<float*>(w);
+  w += up(4 * num_targets);
+  size_t scan_tmp = (size_t)(workspace_bytes - (w - static_cast<char*>(workspace_dev)));
+  // the attention weights of every entry + grad_a_src / grad_a_dst (no input gradient by atomics)
+  if (num_targets > 0)
+    SPP_TRY(gat_aggregate_backward_launch(rowptr_dev, col_dev, num_targets, x_dev, x_is_half, x_stride_elems, K, a_src_dev,
+                                          a_dst_dev, negative_slope, z_dev, row_max_dev, row_sum_dev, grad_z_dev, nullptr,
+                                          grad_a_src_dev, grad_a_dst_dev, alpha_e, alpha_self, stream));
+  // the transposed hop: count, scan, fill
+  SPP_HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(num_sources + 1), st));
+  const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(num_targets, kAggNT));
+  if (num_targets > 0)
+    hipLaunchKernelGGL(k_tr_count, dim3(gt), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, cnt, inv);
+  SPP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w, scan_tmp, cnt, start, (int)(num_sources + 1), st));
+  SPP_HIP_TRY(hipMemsetAsync(cnt, 0, 4 * (size_t)(num_sources + 1), st));
+  if (num_targets > 0)
+    hipLaunchKernelGGL(k_tr_fill_e, dim3(gt), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, start, cnt, ttgt, tedge);
+  const int lpr_log2 = lanes_log2(K / 4);
+  const unsigned grid = (unsigned)ceil_div(num_sources << lpr_log2, kAggNT);
+  hipLaunchKernelGGL(k_gat_gx_gather, dim3(grid), dim3(kAggNT), 0, st, start, ttgt, tedge, alpha_e, alpha_self, num_targets,
+                     num_sources, grad_z_dev, K, lpr_log2, grad_a_src_dev, grad_a_dst_dev, v_src_dev, v_dst_dev, grad_x_dev);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -224,18 +224,20 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, int32_t nb_log2) {
   return nb_log2 ? (hash_node(key) >> (32 - nb_log2)) : 0u;
 }
 
-__device__ __forceinline__ uint32_t lds_slot_of(uint32_t key, int lds_log2) {
-  return (key * 0x85EBCA6Bu) >> (32 - lds_log2);  // second multiplicative hash: independent of the bucket bits
+// Slot of `key` in a table of NS slots (NS need not be a power of two: multiply-shift range reduction of a second
+// multiplicative hash, independent of the bucket bits).
+template <int NS>
+__device__ __forceinline__ uint32_t lds_slot_of(uint32_t key) {
+  return (uint32_t)(((unsigned long long)(key * 0x85EBCA6Bu) * (unsigned long long)NS) >> 32);
 }
 
 // Insert-or-update with min (kMax = false) / max (kMax = true) on the value; *ovf is set when the
 // table is full.  LDS atomics of one workgroup are coherent, the pre-read only saves atomics.
-template <bool kMax>
-__device__ __forceinline__ void lds_upsert(unsigned long long* tab, uint32_t mask, int lds_log2, uint32_t key,
-                                           uint32_t val, int* ovf) {
+template <bool kMax, int NS>
+__device__ __forceinline__ void lds_upsert(unsigned long long* tab, uint32_t key, uint32_t val, int* ovf) {
   const unsigned long long entry = ((unsigned long long)key << 32) | val;
-  uint32_t h = lds_slot_of(key, lds_log2);
-  for (uint32_t probes = 0; probes <= mask; ++probes) {
+  uint32_t h = lds_slot_of<NS>(key);
+  for (uint32_t probes = 0; probes < (uint32_t)NS; ++probes) {
     unsigned long long cur = tab[h];
     if (cur == kEmptySlot) {
       cur = atomicCAS(&tab[h], kEmptySlot, entry);
@@ -250,19 +252,19 @@ __device__ __forceinline__ void lds_upsert(unsigned long long* tab, uint32_t mas
       }
       return;
     }
-    h = (h + 1) & mask;
+    h = (h + 1 == (uint32_t)NS) ? 0u : h + 1;
   }
   *ovf = 1;
 }
 
-__device__ __forceinline__ uint32_t lds_find(const unsigned long long* tab, uint32_t mask, int lds_log2,
-                                             uint32_t key) {
-  uint32_t h = lds_slot_of(key, lds_log2);
-  for (uint32_t probes = 0; probes <= mask; ++probes) {
+template <int NS>
+__device__ __forceinline__ uint32_t lds_find(const unsigned long long* tab, uint32_t key) {
+  uint32_t h = lds_slot_of<NS>(key);
+  for (uint32_t probes = 0; probes < (uint32_t)NS; ++probes) {
     const unsigned long long cur = tab[h];
     if ((uint32_t)(cur >> 32) == key && cur != kEmptySlot) return (uint32_t)cur;
     if (cur == kEmptySlot) break;
-    h = (h + 1) & mask;
+    h = (h + 1 == (uint32_t)NS) ? 0u : h + 1;
   }
   return 0xffffffffu;
 }
@@ -1031,15 +1033,14 @@ __device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
 //   value = T + p      : p is the earliest edge position of this hop reaching the node
 // Every edge gets the final value of its node (evals[p]); the earliest edge of every new node appends
 // (node, kPending | p) to the bucket's known list for the later hops.
-template <int LDS_LOG2>
+template <int NS>
 __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t h, DedupGeom g, int32_t cb_log2, int32_t last_hop) {
   SPP_GROUP_BLOCK(gg);
-  __shared__ unsigned long long tab[1 << LDS_LOG2];
+  __shared__ unsigned long long tab[NS];
   __shared__ int32_t fkc[kMaxFinePerCoarse];   // entries of each fine known list at entry
   __shared__ int32_t fnew[kMaxFinePerCoarse];  // nodes this hop appends to each
   __shared__ int ovf;
-  constexpr uint32_t mask = (1u << LDS_LOG2) - 1;
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const SPP_GLOBAL SlotState* st = G(s.st);
   const SPP_GLOBAL unsigned long long* bpairs = G(s.bpairs);
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     pr[u] = i < e1 ? v : kEmptySlot;
   }
   if (work)
-    for (int i = threadIdx.x; i < (1 << LDS_LOG2); i += kNT) tab[i] = kEmptySlot;
+    for (int i = threadIdx.x; i < NS; i += kNT) tab[i] = kEmptySlot;
   if (threadIdx.x == 0) ovf = 0;
   __syncthreads();
   // known nodes: resolve the previous hop's pending ids (its first-occurrence bitmap is overwritten by
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
           e[u] = (e[u] & 0xffffffff00000000ull) | val;
           kl[i0 + u * kWave] = e[u];
         }
-        if (work) lds_upsert<true>(tab, mask, LDS_LOG2, (uint32_t)(e[u] >> 32), val, &ovf);
+        if (work) lds_upsert<true, NS>(tab, (uint32_t)(e[u] >> 32), val, &ovf);
       }
     }
   }
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u)
-    if (pr[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+    if (pr[u] != kEmptySlot) lds_upsert<false, NS>(tab, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
   for (int i0 = e0 + kDedupRegs * kNT + threadIdx.x; i0 < e1; i0 += 4 * kNT) {  // oversized bucket: the rest
     unsigned long long q[4];
 #pragma unroll
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (q[u] != kEmptySlot) lds_upsert<false>(tab, mask, LDS_LOG2, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
+      if (q[u] != kEmptySlot) lds_upsert<false, NS>(tab, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
   }
   __syncthreads();
   if (ovf) {
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   }
   auto resolve = [&](unsigned long long pair, int i) {
     const uint32_t key = (uint32_t)(pair >> 32), p = (uint32_t)pair;
-    const uint32_t val = lds_find(tab, mask, LDS_LOG2, key);
+    const uint32_t val = lds_find<NS>(tab, key);
     res[i] = val;  // bucket order: consecutive lanes, consecutive words (k_hop_flag brings it to position order)
     if (val == T + p && !last_hop) {  // first occurrence of a new node: append to its fine list (no later hop: skip)
       const int32_t lf = (int32_t)bucket_of(key, g.nb_log2) - fb0;
@@ -2532,14 +2533,20 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap, idmask);
       hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap, idmask);
     }
+    // LDS table of k_bucket_dedup: 2048 / 4096 / 8192 / 16384 slots (any size works: multiply-shift slot index).
+    // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
+    // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
+#ifndef SPP_DEDUP_SLOTS12
+#define SPP_DEDUP_SLOTS12 4096
+#endif
     if (s->lds_log2 == 11)
-      hipLaunchKernelGGL(k_bucket_dedup<11>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else if (s->lds_log2 == 13)
-      hipLaunchKernelGGL(k_bucket_dedup<13>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<8192>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     else
-      hipLaunchKernelGGL(k_bucket_dedup<14>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<16384>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
     for (int rep = 0; rep < dup.flag; ++rep)
       hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,

@@ -439,16 +439,29 @@ class _GatLayer(torch.autograd.Function):
         gW = _wgrad(g_out, z)                                                # [N, K]
         g_z = g_out @ W                                                      # [T, K]
         want_gx = ctx.needs_input_grad[0]
-        g_x = torch.zeros((S, K), dtype=torch.float32, device=x.device) if want_gx else None
+        E = col.numel()
+        gather = want_gx and E * K >= (1 << 22) and K % 4 == 0
         g_as = torch.zeros(S, dtype=torch.float32, device=x.device)
         g_ad = torch.empty(T, dtype=torch.float32, device=x.device)
-        nat.check(L.spp_gat_aggregate_backward(_p(rowptr), _p(col), T, _p(x), half, xs, K, _p(a_src), _p(a_dst), slope,
-                                               _p(z), _p(rmax), _p(rsum), _p(g_z), _p(g_x), _p(g_as), _p(g_ad), st))
+        if gather:
+            # input gradient by gather over the transposed hop: no E x K fp32 atomics, no zero fill, and the two
+            # rank-1 terms of the logits (a_src = x v_src, a_dst = x[:T] v_dst) are added in the same pass
+            g_x = torch.empty((S, K), dtype=torch.float32, device=x.device)
+            nbytes = int(L.spp_gat_aggregate_backward_gather_workspace_bytes(T, S, E))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            nat.check(L.spp_gat_aggregate_backward_gather(_p(rowptr), _p(col), T, S, E, _p(x), half, xs, K, _p(a_src),
+                                                          _p(a_dst), slope, _p(z), _p(rmax), _p(rsum), _p(g_z), _p(v[0]),
+                                                          _p(v[1]), _p(g_x), _p(g_as), _p(g_ad), _p(ws), nbytes, st))
+        else:
+            g_x = torch.zeros((S, K), dtype=torch.float32, device=x.device) if want_gx else None
+            nat.check(L.spp_gat_aggregate_backward(_p(rowptr), _p(col), T, _p(x), half, xs, K, _p(a_src), _p(a_dst), slope,
+                                                   _p(z), _p(rmax), _p(rsum), _p(g_z), _p(g_x), _p(g_as), _p(g_ad), st))
         g_v = torch.empty((2, K), dtype=torch.float32, device=x.device)
         nat.check(L.spp_gat_logits_backward(_p(x), half, xs, S, T, K, _p(g_as), _p(g_ad), _p(g_v[0]), _p(g_v[1]), st))
         if want_gx:                                                          # a_src = x v_src, a_dst = x[:T] v_dst
-            g_x.addr_(g_as, v[0])
-            g_x[:T].addr_(g_ad, v[1])
+            if not gather:
+                g_x.addr_(g_as, v[0])
+                g_x[:T].addr_(g_ad, v[1])
             g_x = g_x.to(x.dtype)
         # v = [att_src; att_dst] @ W
         att = torch.stack([att_src, att_dst]).to(torch.float32)
