@@ -541,7 +541,10 @@ def main():
         dist.barrier()
         _trace("barrier passed, timing")
     torch.cuda.synchronize()
-    L.spp_profile_enable(0 if os.environ.get("SPP_BENCH_NO_PROF") == "1" else 1)
+    # live HIP-event timing of the delivery launches: every launch with group delivery (one per 8 batches), every 8th
+    # with per-batch delivery (the two timing events around EVERY ~100 us launch cost the delivery queue ~7 us each time)
+    prof_every = 1 if os.environ.get("SPP_GROUP_DELIVERY", "0") != "0" else 8
+    L.spp_profile_enable(0 if os.environ.get("SPP_BENCH_NO_PROF") == "1" else prof_every)
     # R windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides (the
     # closing bracket of a window is the opening bracket of the next, so the sampler's slots stay full
     # in between).  A single 20-step window is ~3 ms: its closing synchronize also waits for the refill

@@ -47,9 +47,11 @@ const char* spp_last_error(void);
 int spp_device_count(void);
 
 /* Live timing of the HBM-bound kernels with HIP events recorded on the launching stream
- * (bench.py's roofline leg).  spp_profile_enable(1) clears and starts recording,
+ * (bench.py's roofline leg).  spp_profile_enable(n) clears and starts recording: n = 1 times
+ * every launch, n > 1 every n-th launch of a kind (two timing events around a ~100 us kernel cost ~7 us
+ * of idle hardware queue each time: timing EVERY per-batch delivery slowed the pipeline by 5 %), 0 stops.
  * spp_profile_read is BLOCKING and returns the summed duration, launch count and processed
- * units (rows) of one kernel kind. */
+ * units (rows) of the TIMED launches of one kernel kind. */
 #define SPP_PROF_GATHER 0     /* k_gather_rows   (serial_index)              */
 #define SPP_PROF_ASSEMBLE 1   /* k_assemble      (distributed final assembly) */
 #define SPP_PROF_KINDS 2

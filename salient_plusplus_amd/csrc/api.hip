@@ -16,11 +16,14 @@ struct ProfRec {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static int g_prof_every = 1;                 // time every n-th launch of a kind (spp_profile_enable(n))
+static int64_t g_prof_seen[SPP_PROF_KINDS] = {};
 static std::vector<ProfRec> g_prof[SPP_PROF_KINDS];
 
 int prof_begin(int kind, hipStream_t st, int64_t units) {
   if (!g_prof_on) return -1;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if ((g_prof_seen[kind]++ % g_prof_every) != 0) return -1;
   if (g_prof[kind].size() >= (1u << 16)) return -1;
   ProfRec r{};
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
@@ -111,6 +114,8 @@ void spp_profile_enable(int on) {
     v.clear();
   }
   spp::g_prof_on = on != 0;
+  spp::g_prof_every = on > 1 ? on : 1;
+  for (auto& c : spp::g_prof_seen) c = 0;
 }
 
 spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units) {

@@ -107,6 +107,8 @@ struct spp_session {
   int64_t next_to_deliver = 0;           // batch index
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
   int64_t current_group = -1;            // delivered by next_group(), not yet exported
+  int32_t open_slot = -1;                // last slot exported without an event of its own (mid-group), and its stream
+  hipStream_t open_stream = nullptr;
   int64_t blocked_us = 0;
   int64_t blocked_occasions = 0;
   // native exchange (off when tr == nullptr)
@@ -718,6 +720,10 @@ extern "C" void spp_session_destroy(spp_session* s) {
     delete s;
     return;
   }
+  if (s->open_slot >= 0) {  // deliveries of a partly consumed group: they read the slots until they complete
+    (void)hipStreamSynchronize(s->open_stream);
+    s->open_slot = -1;
+  }
   for (auto st : s->streams)
     if (st) (void)hipStreamSynchronize(st);
   // the consumer's last deliveries still read the slots and the exchange buffers: a (pooled) sampler
@@ -891,8 +897,25 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
     SPP_TRY(sampler_deliver(s->sampler, slot, mfg, x_src_dev, x_row_bytes, x_src_stride_bytes, x_out_dev, y_src_dev,
                             y_row_bytes, bs, y_out_dev, nullptr, as_stream(stream)));
   }
-  SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], as_stream(stream)));
-  s->export_recorded[(size_t)slot] = 1;
+  // One marker per GROUP on the delivery stream, not one per batch: deliveries on one stream complete in order, so
+  // the event behind the group's last delivery covers the earlier ones, and every marker between two ~100 us kernels
+  // costs the hardware queue a few microseconds of idle time.  A batch exported on ANOTHER stream than its
+  // predecessor closes the predecessor's run with an event of its own.
+  hipStream_t st = as_stream(stream);
+  const bool last_of_group = (b + 1 == (int64_t)s->ranges.size()) || ((b + 1) % s->G == 0);
+  if (s->open_slot >= 0 && s->open_stream != st) {
+    SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)s->open_slot], s->open_stream));
+    s->export_recorded[(size_t)s->open_slot] = 1;
+    s->open_slot = -1;
+  }
+  if (last_of_group) {
+    SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot], st));
+    s->export_recorded[(size_t)slot] = 1;
+    s->open_slot = -1;
+  } else {
+    s->open_slot = slot;
+    s->open_stream = st;
+  }
   return retire_current(s);
 }
 

@@ -49,7 +49,8 @@ def nccl_world1():
         dist.destroy_process_group()
 
 
-def test_ddp_training_steps_between_consumer_issued_exchanges(nccl_world1, monkeypatch):
+@pytest.mark.parametrize("group_delivery", ["0", "1"])
+def test_ddp_training_steps_between_consumer_issued_exchanges(nccl_world1, group_delivery, monkeypatch):
     """SAGE under DistributedDataParallel, fed by DeviceDistributedPrefetcher over the native exchange on the
     RCCL communicator derived from the process group: every backward issues gradient all-reduces between two
     exchanges, x stays bit-exact, the loss goes down."""
@@ -59,6 +60,7 @@ def test_ddp_training_steps_between_consumer_issued_exchanges(nccl_world1, monke
     from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher
     from salient_plusplus_amd.models import SAGE
     monkeypatch.setenv("SPP_EXCHANGE_ISSUE", "consumer")
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", group_delivery)
     g = _graph()
     n = g["rowptr"].shape[0] - 1
     dev = torch.device("cuda", 0)
@@ -89,8 +91,8 @@ def test_ddp_training_steps_between_consumer_issued_exchanges(nccl_world1, monke
     assert np.mean(losses[-nb:]) < np.mean(losses[:nb])
 
 
-@pytest.mark.parametrize("slots", [4, 16])
-def test_caller_collectives_between_next_calls_two_in_process_ranks(nccl_world1, slots, monkeypatch):
+@pytest.mark.parametrize("slots,group_delivery", [(4, "0"), (16, "0"), (16, "1")])
+def test_caller_collectives_between_next_calls_two_in_process_ranks(nccl_world1, slots, group_delivery, monkeypatch):
     """Two ranks (threads, in-process transport), consumer-issued exchanges; between two next() calls every rank
     runs an all_reduce on the caller's NCCL group (as a DDP backward would) on its own stream."""
     from oracle import oracle as orc
@@ -99,6 +101,7 @@ def test_caller_collectives_between_next_calls_two_in_process_ranks(nccl_world1,
     from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher
     dist = nccl_world1
     monkeypatch.setenv("SPP_EXCHANGE_ISSUE", "consumer")
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", group_delivery)
     g = _graph()
     n = g["rowptr"].shape[0] - 1
     P, nb, bs = 2, 11, 8

@@ -9,7 +9,7 @@ of a short epoch with the oracle:
   * SPP_GROUP_SIZE=3     -- ragged groups, slot-sets of 3;
   * SPP_DEDUP_BUCKET=64  -- many small dedup buckets (coarse/fine bucket runs, 2^11-slot LDS tables);
   * SPP_DEG_TAGS=0       -- plain neighbour ids: the degree pass of hops >= 1 reads the stub headers instead of the tags the nodes bring along;
-  * SPP_GROUP_DELIVERY=0 -- one delivery launch per batch instead of one per group;
+  * SPP_GROUP_DELIVERY=1 -- one delivery launch per sampling group instead of one per batch;
   * SPP_WHATIF_DUP=...   -- the measurement aid that launches the idempotent kernels twice changes nothing."""
 import os
 import subprocess
@@ -67,7 +67,8 @@ print("CHILD_OK", n)
     {"SPP_DEDUP_BUCKET": "64"},
     {"SPP_DEG_TAGS": "0"},
     {"SPP_DEG_TAGS": "1", "SPP_GROUP_SIZE": "2", "SPP_DEDUP_BUCKET": "64"},
-    {"SPP_GROUP_DELIVERY": "0"},
+    {"SPP_GROUP_DELIVERY": "1"},
+    {"SPP_GROUP_DELIVERY": "1", "SPP_GROUP_SIZE": "3", "SPP_LOOKAHEAD_GROUPS": "1"},
     {"SPP_WHATIF_DUP": "count,pick,tiles,flag,rows"},
     {"SPP_RNG_ARENA_MB": "0", "SPP_GROUP_SIZE": "5", "SPP_XCD_AFFINITY": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))

@@ -149,11 +149,12 @@ def test_group_and_batch_calls_mix_only_at_group_boundaries(fs, graph_a):
         L.spp_session_destroy(h)
 
 
-def test_ready_event_belongs_to_the_batchs_own_group(fs, graph_a):
+def test_ready_event_belongs_to_the_batchs_own_group(fs, graph_a, monkeypatch):
     """DevicePrefetcher waits for the event of the group the batch came from, and the look-ahead keeps the NEXT
     group's delivery queued behind it: every batch must be complete when its event has fired."""
     from salient_plusplus_amd.fast_trainer.samplers import FastSampler
     from salient_plusplus_amd.fast_trainer.transferers import DevicePrefetcher
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", "1")
     dev = torch.device("cuda", 0)
     n = graph_a["rowptr"].shape[0] - 1
     ids_as_x = np.arange(n, dtype=np.float32).reshape(n, 1)

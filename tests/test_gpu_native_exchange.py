@@ -137,6 +137,16 @@ def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots, issue, mo
     assert all(stats[r] > 0 for r in range(P))     # counts / ids / rows really travelled
 
 
+@pytest.mark.parametrize("P,use_cache,nb,bs,slots", [(2, True, 7, 16, 4), (3, True, 5, 24, 16), (8, True, 9, 8, 32),
+                                                     (2, True, 37, 4, 32)])
+@pytest.mark.parametrize("issue", ["thread", "consumer"])
+def test_native_exchange_with_group_delivery(P, use_cache, nb, bs, slots, issue, monkeypatch):
+    """the same exchange with one delivery launch per GROUP (SPP_GROUP_DELIVERY=1): the look-ahead is taken at a fixed,
+    blocking program point on every rank, the assembly of all of a group's batches runs in one launch"""
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", "1")
+    test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots, issue, monkeypatch)
+
+
 def test_rccl_world1_comm_and_session():
     """ncclCommInitRank through the late-bound RCCL, then a distributed Session on it (no peers:
     every row is local, but the counts all-gather and the assembly launch run)."""
