@@ -648,7 +648,9 @@ def main():
     if rank == 0:
         # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
         row_bytes = F * 2
-        alg_bytes_per_row = 2 * row_bytes + 8          # read row + write row + int64 index
+        # read row + write row + the index (int64 at the boundary); the assembly of the partitioned path
+        # reads an 8-byte {bucket, row} record and the row's own address instead: + 12
+        alg_bytes_per_row = 2 * row_bytes + (12 if distributed else 8)
         # One profiled launch per batch.  N == 1: the fused delivery kernel (x-row gather + the small
         # label gather and int64 widening of the MFG, which are charged to the gather's time but not
         # to its bytes: conservative).  N > 1: the fused assembly kernel.
@@ -664,9 +666,12 @@ def main():
                 "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
-        for pmc_name in ("r02_deliver_pmc_papers.json", "r01_gather_pmc_papers.json", "r01_gather_pmc.json"):
+        # (the partitioned path's delivery -- assembly from {local, received, cache} rows -- has a pass of its own)
+        pmc_files = ("r03_deliver_partitioned_pmc.json",) if distributed else \
+            ("r03_deliver_pmc_papers.json", "r02_deliver_pmc_papers.json", "r01_gather_pmc_papers.json", "r01_gather_pmc.json")
+        for pmc_name in pmc_files:
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-            if distributed or not os.path.exists(pmc_path):
+            if (distributed and not native) or not os.path.exists(pmc_path):
                 continue
             pmc = json.load(open(pmc_path))
             if pmc["shape"]["row_bytes"] == row_bytes:
