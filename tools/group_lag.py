@@ -15,7 +15,7 @@ for r in csv.DictReader(open(path)):
     if "k_deliver" in n:
         dl.append((s, e))
     else:
-        ch.append((s, e, q, "k_seed_init" in n))
+        ch.append((s, e, q, ("k_seed_init" in n or "k_hop0_fused" in n)))
 dl.sort()
 ch.sort()
 # chains: per queue, a k_seed_init opens one; it ends with the last kernel before the queue's next k_seed_init

@@ -26,7 +26,7 @@ for q, lst in sorted(by_q.items()):
         continue
     chains, cur = [], None
     for s, e, n in lst:
-        if n.startswith("k_seed_init"):
+        if (n.startswith("k_seed_init") or n.startswith("k_hop0_fused")):
             if cur:
                 chains.append(cur)
             cur = [s, e]
@@ -44,7 +44,7 @@ for q, lst in by_q.items():
         continue
     cur = None
     for s, e, n in lst:
-        if n.startswith("k_seed_init"):
+        if (n.startswith("k_seed_init") or n.startswith("k_hop0_fused")):
             if cur:
                 allch.append(cur)
             cur = [s, e, q]

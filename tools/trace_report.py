@@ -25,7 +25,7 @@ deliver = [x for x in rows if x[2].startswith("k_deliver")]
 per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 8     # batches per sampling / delivery group
 if not deliver:
     # sampling only (tools/microbench.py chain): the window is the last n batches' worth of k_seed_init launches
-    seeds = [x for x in rows if x[2].startswith("k_seed_init")]
+    seeds = [x for x in rows if (x[2].startswith("k_seed_init") or x[2].startswith("k_hop0_fused"))]
     k = max(1, min(len(seeds) - 1, nlast // per_launch))
     lo, hi = seeds[-k - 1][0], seeds[-1][0]
     nlast = k * per_launch
