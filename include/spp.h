@@ -135,6 +135,11 @@ typedef struct spp_sampler_cfg {
   int32_t replace;             /* 1: sample WITH replacement (sample_cpu.hpp:74-82; only the free
                                   sample_adj exposes it, multilayer_sample passes false) */
   spp_partition_cfg part;      /* part.num_parts = 0: plain (single-GPU) batches */
+  int64_t graph_generation;    /* The tables derived from (rowptr_dev, col_dev) -- the degree-tagged int32 neighbour
+                                  array and the row stubs -- are shared by the samplers created over the same arrays AND
+                                  the same generation.  A caller that rewrites the graph in place, or frees it and may get
+                                  another graph of equal size at the same address, passes a new value (0 is fine for a
+                                  graph that never changes). */
 } spp_sampler_cfg;
 
 /* counts of one sampled batch; hops in OUTPUT order (outermost first, after the
@@ -168,7 +173,8 @@ typedef struct spp_mfg_out {
 /* rowptr_dev / col_dev must stay valid AND unchanged for the sampler's lifetime: an int32 copy of the
  * neighbour array and a row-stub table (degree, row start and first neighbours of every node in one
  * 128-byte record; SPP_ROW_STUBS=0 disables it, it is skipped when HBM is short) are derived from them
- * once and shared by the samplers created over the same arrays.  The cache map of a spp_partition_cfg may
+ * once and shared by the samplers created over the same arrays and graph_generation
+ * (spp_sampler_workspace_bytes includes them and the mt19937 arena).  The cache map of a spp_partition_cfg may
  * be rewritten between Sessions (its membership bits are rebuilt by spp_session_create). */
 spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler** out);
 void spp_sampler_destroy(spp_sampler* s);

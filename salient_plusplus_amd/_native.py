@@ -26,7 +26,8 @@ class PartitionCfg(C.Structure):
 class SamplerCfg(C.Structure):
     _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
                 ("num_hops", i32), ("sizes", i64 * SPP_MAX_HOPS), ("max_batch", i64),
-                ("num_slots", i32), ("device", i32), ("replace", i32), ("part", PartitionCfg)]
+                ("num_slots", i32), ("device", i32), ("replace", i32), ("part", PartitionCfg),
+                ("graph_generation", i64)]
 
 
 class MfgCounts(C.Structure):

@@ -1812,7 +1812,7 @@ struct Col32 {
   }
 };
 static std::mutex g_col32_mu;
-static std::map<std::tuple<const void*, int64_t, int>, std::weak_ptr<Col32>> g_col32;
+static std::map<std::tuple<const void*, int64_t, int, int64_t>, std::weak_ptr<Col32>> g_col32;  // (col, nnz, device, generation)
 
 // row stubs of a graph (k_build_stubs), shared like the int32 neighbour array
 struct RowStubs {
@@ -1824,7 +1824,7 @@ struct RowStubs {
     if (p) (void)hipFree(p);
   }
 };
-static std::map<std::tuple<const void*, const void*, int64_t, int>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
+static std::map<std::tuple<const void*, const void*, int64_t, int, int64_t>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
 
 struct SlotHost {
   SlotPtrs p{};
@@ -2088,7 +2088,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     const char* e = getenv("SPP_COL32");
     if (!e || atoi(e) != 0) {
       std::lock_guard<std::mutex> lk(g_col32_mu);
-      const auto key = std::make_tuple((const void*)cfg->col_dev, cfg->nnz, (int)cfg->device);
+      const auto key = std::make_tuple((const void*)cfg->col_dev, cfg->nnz, (int)cfg->device, cfg->graph_generation);
       std::shared_ptr<Col32> c = g_col32[key].lock();
       if (!c) {
         c = std::make_shared<Col32>();
@@ -2141,7 +2141,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     const int mode = e ? atoi(e) : -1;
     const size_t need = sizeof(int32_t) * kStubInts * (size_t)cfg->num_nodes;
     std::lock_guard<std::mutex> lk(g_col32_mu);
-    const auto key = std::make_tuple((const void*)cfg->rowptr_dev, (const void*)cfg->col_dev, cfg->nnz, (int)cfg->device);
+    const auto key = std::make_tuple((const void*)cfg->rowptr_dev, (const void*)cfg->col_dev, cfg->nnz, (int)cfg->device,
+                                    cfg->graph_generation);
     std::shared_ptr<RowStubs> c = g_stubs[key].lock();
     if (!c && mode != 0) {
       size_t free_b = 0, total_b = 0;
@@ -2369,6 +2370,12 @@ spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, 
   const int64_t stride_w = (s->dcap + kMtSlack + 31) / 32 * 32;  // 128-B aligned streams
   const int64_t need = stride_w * nb;
   if (need > budget_words) return SPP_OK;
+  if (need > s->rng_arena_words && !getenv("SPP_RNG_ARENA_MB")) {
+    // no explicit budget: a new arena may take at most a quarter of the HBM that is free right now (the row stubs
+    // follow the same rule); otherwise the streams are generated per group into the slots
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)need * 4 > free_b / 4) return SPP_OK;
+  }
   const bool same = (int64_t)s->rng_arena_seeds.size() == nb && s->rng_arena_stride == stride_w &&
                     std::equal(seeds, seeds + nb, s->rng_arena_seeds.begin());
   if (!same) {

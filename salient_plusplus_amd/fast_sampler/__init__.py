@@ -146,10 +146,21 @@ def _stride_bytes(t: Optional[torch.Tensor]) -> int:
 _resident = _ResidentCache()
 
 
+_graph_epoch = 0
+
+
 def clear_resident_cache():
     """Drop every HBM copy made for host tensors (graph, features) and every pooled sampler."""
+    global _graph_epoch
     _resident.clear()
     _SamplerPool.clear()
+    _graph_epoch += 1          # graphs uploaded from now on never share derived tables with earlier ones
+
+
+def _graph_generation(rowptr_d: torch.Tensor, col_d: torch.Tensor) -> int:
+    """spp_sampler_cfg.graph_generation: changes when the resident cache was cleared (another graph may sit at the
+    same address) and when torch saw an in-place write to the graph tensors (their version counters)."""
+    return (_graph_epoch << 32) + ((int(rowptr_d._version) + int(col_d._version)) & 0xffffffff)
 
 
 def _as_i64_list(sizes: Sequence[int]) -> List[int]:
@@ -379,7 +390,8 @@ class _SamplerPool:
     def acquire(cls, rowptr_d, col_d, sizes, max_batch, slots, device, replace=False, part=None):
         """`part`: None or (PartitionCfg, hashable key, tensors to keep alive) -- ownership bucketing
         fused into the sampling chain (distributed Sessions)."""
-        key = (rowptr_d.data_ptr(), col_d.data_ptr(), tuple(sizes), device, bool(replace),
+        gen = _graph_generation(rowptr_d, col_d)
+        key = (rowptr_d.data_ptr(), col_d.data_ptr(), gen, tuple(sizes), device, bool(replace),
                part[1] if part is not None else None)
         with cls._lock:
             lst = cls._pool.setdefault(key, [])
@@ -395,6 +407,7 @@ class _SamplerPool:
             cfg.sizes[i] = s
         cfg.max_batch, cfg.num_slots, cfg.device = max_batch, slots, device
         cfg.replace = int(bool(replace))
+        cfg.graph_generation = gen
         if part is not None:
             cfg.part = part[0]
         h = C.c_void_p()

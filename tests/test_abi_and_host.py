@@ -174,3 +174,24 @@ def test_range_partition_book_host_side(golden_dir):
     np.testing.assert_array_equal(pb.nid2localnid(nids, 2).numpy(), p["localnid_p2"])
     np.testing.assert_array_equal(pb.partid2nids(1).numpy(), p["partid2nids_1"])
     assert pb.nid_is_local(torch.tensor([1499, 1500, 2099, 2100])).tolist() == [False, True, True, False]
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` starts its own ranks (children, before anything touches the GPU); on a box with
+    fewer GPUs it says so and exits non-zero within seconds instead of measuring one GPU and calling it N."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing to run fewer ranks" in r.stderr
+    assert r.stdout.strip() == ""                       # no JSON line that could be mistaken for a measurement
+    assert time.time() - t0 < 60
+    # a launcher that started another number of ranks than --gpus says is refused as well
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
