@@ -687,25 +687,6 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       }
     }
   }
-  if constexpr (kCoop && kHdr) {
-    // header {degree, row start lo, hi} of lane L's row: words 0..2 of the piece lane (L & 7) * 8 holds in round L >> 3
-    const int lane = threadIdx.x & (kWave - 1);
-    const int src = (lane & 7) * 8;
-    int32_t hd = 0, hlo = 0, hhi = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int32_t d = __shfl(seg[r].x, src, kWave), lo = __shfl(seg[r].y, src, kWave), hi = __shfl(seg[r].z, src, kWave);
-      if ((lane >> 3) == r) {
-        hd = d;
-        hlo = lo;
-        hhi = hi;
-      }
-    }
-    if (i < T) {
-      deg = hd;
-      rs = ((int64_t)hhi << 32) | (uint32_t)hlo;
-    }
-  }
   int32_t pre0, pre1, tot0, tot1;
   if (self_prefix) {
     block_exclusive_scan<int32_t, kNT>(a0, lds_scan[0], &pre0);
@@ -758,6 +739,33 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     return;
   }
   const int tid = threadIdx.x;
+  // kHdr: the first eight draws are requested BEFORE the row's header is taken out of its stub line (the first use
+  // of the line, i.e. the wait for it): stub line, offset sums and draws then share one round trip again, as they did
+  // when the exact degree came from the degree pass
+  uint32_t rfirst[8];
+  if constexpr (kHdr) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rfirst[u] = rng[u < f ? u : (f > 0 ? f - 1 : 0)];  // (lanes that draw nothing read the stream's start)
+  }
+  if constexpr (kCoop && kHdr) {
+    // header {degree, row start lo, hi} of lane L's row: words 0..2 of the piece lane (L & 7) * 8 holds in round L >> 3
+    const int lane = threadIdx.x & (kWave - 1);
+    const int src = (lane & 7) * 8;
+    int32_t hd = 0, hlo = 0, hhi = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int32_t d = __shfl(seg[r].x, src, kWave), lo = __shfl(seg[r].y, src, kWave), hi = __shfl(seg[r].z, src, kWave);
+      if ((lane >> 3) == r) {
+        hd = d;
+        hlo = lo;
+        hhi = hi;
+      }
+    }
+    if (live) {
+      deg = hd;
+      rs = ((int64_t)hhi << 32) | (uint32_t)hlo;
+    }
+  }
   if (smp) {
     // Robert Floyd (sample_cpu.hpp:97-110): for j = deg-f .. deg-1: option = gen() % j;
     // winner = option unless already chosen, then j.  The draws of 8 steps are loaded before the first
@@ -766,7 +774,8 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     for (int32_t k0 = 0; k0 < f; k0 += 8) {
       uint32_t r[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r[u] = rng[k0 + u < f ? k0 + u : f - 1];  // clamped, not predicated: the 8 loads issue back to back
+      for (int u = 0; u < 8; ++u)  // clamped, not predicated: the 8 loads issue back to back
+        r[u] = (kHdr && k0 == 0) ? rfirst[u] : rng[k0 + u < f ? k0 + u : f - 1];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int32_t k = k0 + u;
