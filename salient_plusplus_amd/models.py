@@ -212,15 +212,31 @@ class SAGE(torch.nn.Module):
 
 
 def _wgrad(g, a):
-    """g.T @ a for very tall g [T, N], a [T, K]: batched over row slabs and summed (see _TallLinear)"""
+    """g.T @ a for very tall g [T, N], a [T, K]: batched over row slabs and summed (see _TallLinear).  64 slabs of
+    >= 2048 rows in the a.T @ g order are what the library runs fastest at T = 164 k, N = K = 256 (162 us against 174-181
+    for 32 slabs and 483 for the single product; tools/gemm_variants.py)"""
     T = a.size(0)
-    slabs = min(64, T // 4096)
+    slabs = min(64, T // 2048)
     if slabs < 2:
         return g.t() @ a
     c = T // slabs
-    out = torch.bmm(g[:slabs * c].view(slabs, c, -1).transpose(1, 2), a[:slabs * c].view(slabs, c, -1)).sum(0)
+    out = torch.bmm(a[:slabs * c].view(slabs, c, -1).transpose(1, 2), g[:slabs * c].view(slabs, c, -1)).sum(0).t()
     if slabs * c < T:
-        out.addmm_(g[slabs * c:].t(), a[slabs * c:])
+        out = out + g[slabs * c:].t() @ a[slabs * c:]
+    return out
+
+
+def _tall_linear(a, w):
+    """a @ w.T for a very tall a [T, K]: in four row chunks the library picks a tile that runs 13 % faster than for the
+    single product at T = 164 k, N = K = 256 (206 against 236 us; tools/gemm_variants.py)"""
+    T = a.size(0)
+    if T < (1 << 16):
+        return a @ w.t()
+    out = torch.empty((T, w.size(0)), dtype=a.dtype, device=a.device)
+    wt = w.t().contiguous()
+    c = -(-T // 4)
+    for i in range(0, T, c):
+        torch.mm(a[i:i + c], wt, out=out[i:i + c])
     return out
 
 
@@ -262,7 +278,7 @@ class _SageStack(torch.autograd.Function):
                 nat.check(L.spp_sage_operand_forward_act(_p(rowptr), _p(col), T, _p(h), K, _p(A), 2 * K, float(p),
                                                          int(bool(training)), seeds[i - 1], st))
             W = torch.cat([weights[2 * i], weights[2 * i + 1]], dim=1)          # [N, 2K] = [W_l | W_r]
-            Z = A @ W.t()
+            Z = _tall_linear(A, W)
             operands.append(A)
             wcats.append(W)
             if i != n_layers - 1:
