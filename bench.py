@@ -52,7 +52,7 @@ def parse():
                     help="S-papers (default: the dataset BASELINE.json's metric is quoted on; 56 GB of graph + "
                          "features fit one MI355X), S-products (configs[1]), S-arxiv, S-tiny")
     ap.add_argument("--slots", type=int, default=0,
-                    help="batch slots in flight (0 = 32: 4 slot-sets of 8)")
+                    help="batch slots in flight (0 = 64: 4 slot-sets of 16)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model-step", action="store_true",
@@ -365,7 +365,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or a.force_distributed
     if a.slots <= 0:
-        a.slots = int(os.environ.get("SPP_MAX_SLOTS", "32"))
+        a.slots = int(os.environ.get("SPP_MAX_SLOTS", "64"))
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -578,9 +578,10 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
 
   bool generic = false;
   for (int h = 0; h < cfg->num_hops; ++h) generic |= (cfg->sizes[h] < 0 || cfg->sizes[h] > 32);
-  // auto: two slot-sets of up to 8 batches (each set-stream then owns a hardware queue; measured
-  // best on MI355X: 16 slots = 2 x 8), smaller groups only when fewer slots are allowed
-  int G = cfg->group_size > 0 ? cfg->group_size : std::max(1, std::min(8, M / 2));
+  // auto: four slot-sets of up to 16 batches when 32 or more slots are allowed (64 slots = 4 x 16 measured best on
+  // MI355X at papers and products scale: the small hops of a chain are latency bound, so a launch over 16 batches
+  // costs little more than one over 8 -- profiles/r03_ab_INDEX.md), two sets of up to 8 below that
+  int G = cfg->group_size > 0 ? cfg->group_size : (M >= 32 ? std::min(16, M / 4) : std::max(1, std::min(8, M / 2)));
   G = std::min(G, std::min(M, kMaxGroup));
   if (generic) G = 1;
   int sets = std::max(1, std::min(M / G, kMaxSets));
