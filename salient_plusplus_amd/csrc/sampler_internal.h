@@ -63,7 +63,10 @@ class Worker {
 // the sampler's two persistent host threads: 0 = chain launcher, 1 = exchange issuer
 Worker* sampler_worker(spp_sampler* s, int which);
 
-constexpr int kMaxGroup = 16;       // batches one launch can process (blockIdx.y)
+#ifndef SPP_MAX_GROUP
+#define SPP_MAX_GROUP 16
+#endif
+constexpr int kMaxGroup = SPP_MAX_GROUP;  // batches one launch can process (the grids are flattened: GroupGrid)
 constexpr int kMaxWorkStreams = 4;  // sampling streams owned by a sampler (slot-sets share them round-robin)
 constexpr int kMaxSets = 8;         // slot-sets (groups sampled, exchanged or waiting for the consumer) in flight
 
