@@ -72,7 +72,7 @@ def parse():
                          "launcher's default) or on a 1/N slice of one global permutation")
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps run back to back, pipeline kept full in between; the "
-                         "reported ms_per_step / value are the MEDIAN window's (0 = max(6, 2 * ceil(128 / steps)): an even count)")
+                         "reported ms_per_step / value are the MEAN over all windows (0 = max(6, 2 * ceil(128 / steps)))")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -121,10 +121,11 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=24, warm=8, windows=6, hip=True, arch="sage", ddp=False):
+def model_step_timing(feeder, F, n_classes, steps=48, warm=16, windows=4, hip=True, arch="sage", ddp=False):
     """ms/step of fwd+bwd+Adam with one resident batch re-used, and with the data path feeding it (the
     training step of fast_trainer/train.py:15-71).  Measured like the data path: `windows` back-to-back
-    windows of `steps` steps, the MEDIAN window reported and all of them kept -- a fresh process pays a few
+    windows of `steps` steps after `warm` untimed ones, reported: the MEAN over all windows (their total
+    time / their total steps) with every window kept in the line -- a fresh process pays a few
     multi-millisecond allocator growths while the model's batch-size-dependent temporaries meet their
     largest shapes, and one 24-step sample after 4 warm-up steps (round 2) carried them into the figure.
     hip=True: salient_plusplus_amd.models (HIP message passing); False: the plain-torch formulation
@@ -166,14 +167,12 @@ def model_step_timing(feeder, F, n_classes, steps=24, warm=8, windows=6, hip=Tru
             if show:
                 print(f"[bench] model step ({tag}) window {w}: {out[-1]:.3f} ms/step; host us per step " +
                       " ".join(f"{v:.0f}" for v in host), file=sys.stderr, flush=True)
-        srt = sorted(out)
-        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-        return med, out
+        return sum(out) / len(out), out
 
     fixed = feeder.next()
     m_only, w_only = run_windows(lambda: fixed, "resident batch")
     m_data, w_data = run_windows(feeder.next, "with data path")
-    detail = {"windows": windows, "steps_each": steps, "warmup_steps": warm, "reported": "median window",
+    detail = {"windows": windows, "steps_each": steps, "warmup_steps": warm, "reported": "mean over all windows",
               "model_only_ms_all": [round(v, 4) for v in w_only], "with_data_path_ms_all": [round(v, 4) for v in w_data]}
     return m_only, m_data, detail
 
@@ -548,11 +547,8 @@ def main():
     # R windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides (the
     # closing bracket of a window is the opening bracket of the next, so the sampler's slots stay full
     # in between).  A single 20-step window is ~3 ms: its closing synchronize also waits for the refill
-    # chains the sampler has in flight, which makes one short window noisy.  Reported: the median window.
-    # An EVEN number of windows: when K is not a multiple of the sampler's group of 8 batches the windows
-    # alternate between two phases (how late in the window the last refill chain starts: 0.147 / 0.163 ms per
-    # step at K = 20), and with an odd count the median is simply the phase of the first window.  With an even
-    # count the median is the mean of the two middle windows -- one of each phase.
+    # chains the sampler has in flight, which makes one short window noisy.  Reported: the mean over all windows
+    # (every window is in the line).
     R = a.windows if a.windows > 0 else max(6, 2 * -(-128 // max(1, a.steps)))
     xb0 = feeder.exchange_bytes()
     win = []                                      # (seconds, edges, nodes) per window
@@ -596,9 +592,13 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)                   # whole-job edges / nodes
         stats = torch.cat([tmax.unsqueeze(1), tot], dim=1)
     win = stats.cpu().tolist()
-    order = sorted(range(R), key=lambda k: win[k][0])
-    mids = [order[R // 2]] if R % 2 else [order[R // 2 - 1], order[R // 2]]
-    dt, edges, nodes = (sum(win[k][j] for k in mids) / len(mids) for j in range(3))
+    # reported: the MEAN window, i.e. the whole timed region / all its steps (value x steps x windows reproduces
+    # timed_region_s).  The median stays in the line: with K not a multiple of the sampler's group the windows differ by
+    # where their closing synchronize catches the refill chains (every 4th of the 20-step windows is ~25 % longer with
+    # groups of 16), and a median would simply leave those out.
+    dt, edges, nodes = (sum(w[j] for w in win) / R for j in range(3))
+    srt = sorted(w[0] for w in win)
+    dt_median = srt[R // 2] if R % 2 else 0.5 * (srt[R // 2 - 1] + srt[R // 2])
     window_ms = [w[0] / a.steps * 1e3 for w in win]
     timed_total_s = sum(w[0] for w in win)
 
@@ -688,8 +688,9 @@ def main():
             "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
-            "windows": {"n": R, "steps_each": a.steps, "reported": "median window (even count: mean of the two middle windows)",
-                        "ms_per_step_min": min(window_ms), "ms_per_step_median": dt / a.steps * 1e3,
+            "windows": {"n": R, "steps_each": a.steps, "reported": "mean over all windows (timed_region_s / all steps)",
+                        "ms_per_step_min": min(window_ms), "ms_per_step_median": dt_median / a.steps * 1e3,
+                        "ms_per_step_mean": dt / a.steps * 1e3,
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
                         "ms_per_step_all": [round(v, 5) for v in window_ms]},
             "timed_region_s": timed_total_s,          # all R windows (also under "windows")

@@ -28,8 +28,8 @@ done
 python3 tools/pmc_gather_report.py "$out/g_FETCH_SIZE_counter_collection.csv" "$out/g_WRITE_SIZE_counter_collection.csv" 256 "$out/${tag}_deliver_pmc_papers.json" 256 947000 111059956
 for c in FETCH_SIZE WRITE_SIZE; do (head -1 "$out/g_${c}_counter_collection.csv"; grep "spp::" "$out/g_${c}_counter_collection.csv") > "$out/${tag}_gather_pmc_papers_${c}.csv"; rm -f "$out"/g_${c}_*; done
 # sampling only
-CHAIN_CFG=32,8 WL=S-papers timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out" -o chain -- python3 tools/microbench.py chain > "$out/${tag}_chain_only.log" 2>&1 || exit 1
-f=$(find "$out" -name "chain_kernel_trace.csv" | head -1); python3 tools/trace_report.py "$f" 256 8 > "$out/${tag}_chain_only_trace_report.txt"; rm -f "$f" "$out"/chain_agent_info.csv
+CHAIN_CFG=${CHAIN_CFG:-64,16} WL=S-papers timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out" -o chain -- python3 tools/microbench.py chain > "$out/${tag}_chain_only.log" 2>&1 || exit 1
+f=$(find "$out" -name "chain_kernel_trace.csv" | head -1); python3 tools/trace_report.py "$f" 256 ${CHAIN_GROUP:-16} > "$out/${tag}_chain_only_trace_report.txt"; rm -f "$f" "$out"/chain_agent_info.csv
 grep "chain only" "$out/${tag}_chain_only.log" >> "$out/${tag}_chain_only_trace_report.txt"
 # model step
 for m in sage gat; do
