@@ -121,7 +121,7 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=48, warm=16, windows=4, hip=True, arch="sage", ddp=False):
+def model_step_timing(feeder, F, n_classes, steps=64, warm=16, windows=6, hip=True, arch="sage", ddp=False):
     """ms/step of fwd+bwd+Adam with one resident batch re-used, and with the data path feeding it (the
     training step of fast_trainer/train.py:15-71).  Measured like the data path: `windows` back-to-back
     windows of `steps` steps after `warm` untimed ones, reported: the MEAN over all windows (their total

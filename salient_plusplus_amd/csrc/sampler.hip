@@ -1820,6 +1820,21 @@ struct Col32 {
     }
   }
 };
+// Streams of the data path.  SPP_STREAM_PRIORITY=low puts them below the consumer's stream (torch's current stream has
+// the default priority): the dispatcher then hands the model step's kernels out first and the data path takes what is left
+static hipError_t create_data_stream(hipStream_t* st) {
+  static const int prio = [] {
+    const char* e = getenv("SPP_STREAM_PRIORITY");
+    if (!e || !*e) return 0;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
+    if (!strcmp(e, "low")) return least;
+    if (!strcmp(e, "high")) return greatest;
+    return atoi(e);
+  }();
+  return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
 static std::mutex g_col32_mu;
 static std::map<std::tuple<const void*, int64_t, int, int64_t>, std::weak_ptr<Col32>> g_col32;  // (col, nnz, device, generation)
 
@@ -2210,7 +2225,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     }
   }
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
-  if (rc == SPP_OK && hipStreamCreateWithFlags(&s->deliver_stream, hipStreamNonBlocking) != hipSuccess) {
+  if (rc == SPP_OK && create_data_stream(&s->deliver_stream) != hipSuccess) {
     set_error("spp_sampler_create: stream creation failed");
     rc = SPP_ERR_HIP;
   }
@@ -2339,7 +2354,7 @@ hipStream_t sampler_work_stream(spp_sampler* s, int i) {
     return v < 1 ? 1 : (v > kMaxWorkStreams ? kMaxWorkStreams : v);
   }();
   hipStream_t& st = s->work_streams[i % n_streams];
-  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;  // null stream as last resort
+  if (!st && create_data_stream(&st) != hipSuccess) st = nullptr;  // null stream as last resort
   return st;
 }
 
@@ -2857,7 +2872,7 @@ spp_status sampler_xbuf_counts(spp_sampler* s, XBuf* xb, int64_t bytes) {
 }
 
 hipStream_t sampler_comm_stream(spp_sampler* s) {
-  if (!s->comm_stream && hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking) != hipSuccess)
+  if (!s->comm_stream && create_data_stream(&s->comm_stream) != hipSuccess)
     s->comm_stream = nullptr;
   return s->comm_stream;
 }
