@@ -62,9 +62,13 @@ def parse():
                     help="consumer model of the epoch-time figure (models.py); the plain-torch comparison is SAGE")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the bit-exact check of one group of batches through the native exchange")
-    ap.add_argument("--prime", type=int, default=16,
+    ap.add_argument("--prime", type=int, default=-1,
                     help="steps run as part of set-up, before the W warm-up steps: first-touch costs of the "
-                         "allocators, the pooled sampler workspace and the exchange buffers (reported as priming_steps)")
+                         "allocators, the pooled sampler workspace and the exchange buffers (reported as priming_steps; "
+                         "-1 = 3 x the slots in flight: the consumer loop of this benchmark never waits for the GPU, so it "
+                         "runs up to `slots` deliveries ahead of it and torch's caching allocator keeps growing by one "
+                         "output batch per step until that depth is reached -- at MAG240 scale one of those growths took "
+                         "0.5 s, profiles/r03_bench_mag_stall.txt)")
     ap.add_argument("--cache-strategy", default="vip", choices=["vip", "degree", "degree-desc"],
                     help="N>1: ranking of the remote vertices for the feature cache (ddp.py:425-492)")
     ap.add_argument("--seed-scheme", default="federated", choices=["federated", "global"],
@@ -365,6 +369,8 @@ def main():
     distributed = world > 1 or a.force_distributed
     if a.slots <= 0:
         a.slots = int(os.environ.get("SPP_MAX_SLOTS", "64"))
+    if a.prime < 0:
+        a.prime = 3 * a.slots
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -551,6 +557,9 @@ def main():
     # (every window is in the line).
     R = a.windows if a.windows > 0 else max(6, 2 * -(-128 // max(1, a.steps)))
     xb0 = feeder.exchange_bytes()
+    if os.environ.get("SPP_BENCH_STALL_DUMP"):        # diagnostic: Python stacks of all threads every N seconds of the timed region
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SPP_BENCH_STALL_DUMP"]), repeat=True)
     win = []                                      # (seconds, edges, nodes) per window
     for _w in range(R):
         edges = nodes = 0
@@ -563,6 +572,12 @@ def main():
             nodes += b.x.size(0)
             if step_t is not None:
                 step_t.append((time.perf_counter() - ts) * 1e6)
+                if step_t[-1] > 50000:            # a stall: what the caching allocator did meanwhile
+                    ms_ = torch.cuda.memory_stats(dev)
+                    print(f"[bench] step of {step_t[-1] / 1e3:.0f} ms in window {_w}: torch device allocs {ms_.get('num_device_alloc')} "
+                          f"frees {ms_.get('num_device_free')} retries {ms_.get('num_alloc_retries')} reserved "
+                          f"{torch.cuda.memory_reserved(dev) / 2**30:.1f} GB, free HBM {torch.cuda.mem_get_info(dev)[0] / 2**30:.1f} GB",
+                          file=sys.stderr, flush=True)
         ts = time.perf_counter()
         torch.cuda.synchronize()
         if step_t is not None:                    # diagnostic: host time of every step of a window, and of its closing synchronize
@@ -576,6 +591,8 @@ def main():
         torch.cuda.synchronize()
         win.append((time.perf_counter() - t0, float(edges), float(nodes)))
     xb1 = feeder.exchange_bytes()
+    if os.environ.get("SPP_BENCH_STALL_DUMP"):
+        faulthandler.cancel_dump_traceback_later()
     # gather-kernel time, measured live with HIP events on the launching stream
     ms, n_launch, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
     # SPP_PROF_GATHER: the fused delivery launch (also assembles x with the native exchange);
@@ -694,6 +711,10 @@ def main():
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
                         "ms_per_step_all": [round(v, 5) for v in window_ms]},
             "timed_region_s": timed_total_s,          # all R windows (also under "windows")
+            "hbm": {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
+                    "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+                    "torch_alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+                    "torch_device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))},
             "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,

@@ -11,8 +11,8 @@ timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out" -o "$
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out" -o "${tag}_write" -- python3 bench.py $ARGS > /dev/null 2> "$out/${tag}_write.err" || exit 1
 f=$(find "$out" -name "${tag}_fetch_counter_collection.csv" | head -1)
 w=$(find "$out" -name "${tag}_write_counter_collection.csv" | head -1)
-# batches delivered = k_deliver launches (+ 8 per group launch); batches sampled = k_seed_init launches x 8
-nd=$(( $(grep -c "k_deliver<" "$f") + 8 * $(grep -c "k_deliver_group" "$f") )); ns=$(( $(grep -c "k_seed_init" "$f") * 8 ))
+# batches delivered = k_deliver launches (+ G per group launch); batches sampled = k_seed_init launches x G (G = batches per sampling launch)
+G=${SPP_GROUP_SIZE:-16}; nd=$(( $(grep -c "k_deliver<" "$f") + G * $(grep -c "k_deliver_group" "$f") )); ns=$(( $(grep -c "k_seed_init" "$f") * G ))
 python3 tools/pmc_pipeline_report.py "$f" "$w" "$nd" "$ns" > "$out/${tag}_traffic_per_kernel.txt"
 # keep the spp:: rows only (the torch graph construction dominates the raw files)
 for x in "$f" "$w"; do (head -1 "$x"; grep "spp::" "$x") > "$x.tmp" && mv "$x.tmp" "$x"; done

@@ -39,3 +39,13 @@ for m in sage gat; do
 done
 set +x
 ls -la "$out"
+# the other workloads and legs DESIGN.md quotes (one line each)
+set -x
+timeout -k 10 300 python3 bench.py --workload S-arxiv --no-cpu-baseline --no-model-step > "$out/${tag}_bench_arxiv.json" 2>> "$out/bench.err" || exit 1
+timeout -k 10 300 python3 bench.py --workload S-mag --no-cpu-baseline --no-model-step > "$out/${tag}_bench_mag.json" 2>> "$out/bench.err" || exit 1
+timeout -k 10 400 python3 bench.py --model gat --no-cpu-baseline > "$out/${tag}_bench_papers_gat.json" 2>> "$out/bench.err" || exit 1
+timeout -k 10 400 python3 bench.py --gpus 1 --force-distributed --steps 20 --warmup 5 --no-cpu-baseline > "$out/${tag}_bench_papers_force_distributed_ddp.json" 2>> "$out/bench.err" || exit 1
+SPP_GROUP_DELIVERY=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-model-step > "$out/${tag}_bench_papers_group_delivery.json" 2>> "$out/bench.err" || exit 1
+SPP_GROUP_DELIVERY=1 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-model-step > "$out/${tag}_bench_papers_steps20_group_delivery.json" 2>> "$out/bench.err" || exit 1
+set +x
+ls -la "$out"
