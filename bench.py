@@ -524,9 +524,9 @@ def main():
         feeder = EpochFeeder(make_iter, shuffler, get_idx)
         parallelism = f"dp{world}: features range-partitioned {world}-way, {a.cache_strategy} cache " \
                       f"{a.cache_frac:.0%} of N/P rows ({n_cache}), {a.seed_scheme} seeds, {max(1, n_local // bs)} batches per rank and epoch, " + \
-                      (f"native RCCL exchange per group of 8 batches (all-gather counts, grouped send/recv ids+rows; issued by the "
+                      (f"native RCCL exchange per sampling group (up to 16 batches; all-gather counts, grouped send/recv ids+rows; issued by the "
                        f"{os.environ.get('SPP_EXCHANGE_ISSUE')})"
-                       if native else "torch.distributed all_to_all_single, one exchange per group of 8 batches")
+                       if native else "torch.distributed all_to_all_single, one exchange per sampling group (up to 16 batches)")
 
     # ---- set-up: first-touch costs (allocator segments, workspace, exchange buffers) ----
     _trace("iterator ready, priming")
@@ -546,7 +546,7 @@ def main():
         dist.barrier()
         _trace("barrier passed, timing")
     torch.cuda.synchronize()
-    # live HIP-event timing of the delivery launches: every launch with group delivery (one per 8 batches), every 8th
+    # live HIP-event timing of the delivery launches: every launch with group delivery (one per sampling group), every 8th
     # with per-batch delivery (the two timing events around EVERY ~100 us launch cost the delivery queue ~7 us each time)
     prof_every = 1 if os.environ.get("SPP_GROUP_DELIVERY", "0") != "0" else 8
     L.spp_profile_enable(0 if os.environ.get("SPP_BENCH_NO_PROF") == "1" else prof_every)
