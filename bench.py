@@ -356,6 +356,11 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ.get("SPP_BENCH_TRACE_AFTER", "60")), exit=False)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a))               # before anything here touches the GPU
+    # stdout carries ONE JSON line and nothing else: libraries that announce themselves there (RCCL prints its version
+    # banner to stdout when a communicator is created) are sent to stderr, the line is written to the saved descriptor
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -745,7 +750,8 @@ def main():
             out["cpu_baseline"]["cores_source"] = (f"min(sched_getaffinity = {len(os.sched_getaffinity(0))}, cgroup cpu.max quota) "
                                                    f"= {threads}; os.cpu_count() shows {os.cpu_count()}")
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
