@@ -280,9 +280,10 @@ typedef struct spp_session_cfg {
   int32_t force_exact_num_batches;
   int64_t exact_num_batches;
   int32_t max_items_in_queue;      /* upper bound on batches in flight (slots) */
-  int32_t group_size;              /* batches sampled per launch sequence (0 = auto: max_items/2, <= 8);
-                                      max_items_in_queue / group_size slot-sets are in flight, one HIP
-                                      stream each */
+  int32_t group_size;              /* batches sampled per launch sequence, at most 16 (0 = auto: max_items/4 capped at
+                                      16 when 32 or more slots are allowed, else max_items/2 capped at 8);
+                                      max_items_in_queue / group_size slot-sets (at most 8) are in flight and share
+                                      the sampler's two sampling streams */
   int32_t device;
   /* Optional: borrow an existing sampler (same graph, fanouts; max_batch and num_slots at least
    * what this epoch needs) instead of allocating workspace per epoch -- the counterpart of the
