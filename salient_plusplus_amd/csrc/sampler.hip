@@ -232,13 +232,15 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint32_t key) {
 }
 
 // Insert-or-update with min (kMax = false) / max (kMax = true) on the value; *ovf is set when the
-// table is full.  LDS atomics of one workgroup are coherent, the pre-read only saves atomics.
-template <bool kMax, int NS>
+// table is full.  LDS atomics of one workgroup are coherent, the pre-read only saves atomics: kPreRead = false goes
+// straight to the compare-and-swap (one table operation instead of two for a key that is not in the table yet -- nearly
+// every candidate of the big last hop).
+template <bool kMax, int NS, bool kPreRead = true>
 __device__ __forceinline__ void lds_upsert(unsigned long long* tab, uint32_t key, uint32_t val, int* ovf) {
   const unsigned long long entry = ((unsigned long long)key << 32) | val;
   uint32_t h = lds_slot_of<NS>(key);
   for (uint32_t probes = 0; probes < (uint32_t)NS; ++probes) {
-    unsigned long long cur = tab[h];
+    unsigned long long cur = kPreRead ? tab[h] : kEmptySlot;
     if (cur == kEmptySlot) {
       cur = atomicCAS(&tab[h], kEmptySlot, entry);
       if (cur == kEmptySlot) return;
@@ -1044,8 +1046,10 @@ __device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
 // (node, kPending | p) to the bucket's known list for the later hops.
 template <int NS>
 __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                       int32_t h, DedupGeom g, int32_t cb_log2, int32_t last_hop) {
+                                                       int32_t h, DedupGeom g, int32_t cb_log2, int32_t hop_flags) {
   SPP_GROUP_BLOCK(gg);
+  const int32_t last_hop = hop_flags & 1;    // no later hop: the known lists are not extended
+  const bool no_preread = hop_flags & 2;     // candidates go straight to the compare-and-swap (mostly new keys)
   __shared__ unsigned long long tab[NS];
   __shared__ int32_t fkc[kMaxFinePerCoarse];   // entries of each fine known list at entry
   __shared__ int32_t fnew[kMaxFinePerCoarse];  // nodes this hop appends to each
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
           e[u] = (e[u] & 0xffffffff00000000ull) | val;
           kl[i0 + u * kWave] = e[u];
         }
-        if (work) lds_upsert<true, NS>(tab, (uint32_t)(e[u] >> 32), val, &ovf);
+        if (work) lds_upsert<true, NS, false>(tab, (uint32_t)(e[u] >> 32), val, &ovf);  // known nodes are distinct keys: no pre-read
       }
     }
   }
@@ -1148,7 +1152,10 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u)
-    if (pr[u] != kEmptySlot) lds_upsert<false, NS>(tab, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+    if (pr[u] != kEmptySlot) {
+      if (no_preread) lds_upsert<false, NS, false>(tab, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+      else lds_upsert<false, NS>(tab, (uint32_t)(pr[u] >> 32), T + (uint32_t)pr[u], &ovf);
+    }
   for (int i0 = e0 + kDedupRegs * kNT + threadIdx.x; i0 < e1; i0 += 4 * kNT) {  // oversized bucket: the rest
     unsigned long long q[4];
 #pragma unroll
@@ -1159,7 +1166,7 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (q[u] != kEmptySlot) lds_upsert<false, NS>(tab, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
+      if (q[u] != kEmptySlot) lds_upsert<false, NS, false>(tab, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
   }
   __syncthreads();
   if (ovf) {
@@ -2555,7 +2562,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
-    const int32_t last = (h == H - 1) ? 1 : 0;  // the known lists are not read after the last hop
+    // bit 0: the known lists are not read after the last hop; bit 1: the candidates skip the table pre-read (most edges of
+    // a hop reach nodes that are new to the batch; SPP_DEDUP_PREREAD=1 keeps the pre-read)
+    static const bool dedup_preread = [] {
+      const char* e = getenv("SPP_DEDUP_PREREAD");
+      return e && atoi(e) != 0;
+    }();
+    const int32_t last = ((h == H - 1) ? 1 : 0) | (!dedup_preread ? 2 : 0);
     // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
     const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));

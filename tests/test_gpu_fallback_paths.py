@@ -11,7 +11,8 @@ of a short epoch with the oracle:
   * SPP_DEG_TAGS=0       -- plain neighbour ids: the degree pass of hops >= 1 reads the stub headers instead of the tags the nodes bring along;
   * SPP_GROUP_DELIVERY=1 -- one delivery launch per sampling group instead of one per batch;
   * SPP_WHATIF_DUP=...   -- the measurement aid that launches the idempotent kernels twice changes nothing;
-  * SPP_STREAM_PRIORITY=low, SPP_GROUP_SIZE=16 -- the data path's streams below the consumer's, the largest group."""
+  * SPP_STREAM_PRIORITY=low, SPP_GROUP_SIZE=16 -- the data path's streams below the consumer's, the largest group;
+  * SPP_DEDUP_PREREAD=1  -- the dedup table is read before every compare-and-swap (the form until round 3)."""
 import os
 import subprocess
 import sys
@@ -73,6 +74,7 @@ print("CHILD_OK", n)
     {"SPP_WHATIF_DUP": "count,pick,tiles,flag,rows"},
     {"SPP_RNG_ARENA_MB": "0", "SPP_GROUP_SIZE": "5", "SPP_XCD_AFFINITY": "0"},
     {"SPP_STREAM_PRIORITY": "low", "SPP_GROUP_SIZE": "16"},
+    {"SPP_DEDUP_PREREAD": "1"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_chain_paths_are_bit_exact(env):
     e = dict(os.environ)
