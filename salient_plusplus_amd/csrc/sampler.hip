@@ -1880,7 +1880,7 @@ struct spp_sampler {
   bool any_generic = false;
   DedupGeom geom{};
   int cb_log2[SPP_MAX_HOPS];        // bucket bits of hop h (<= geom.nb_log2; fewer for small hops)
-  int lds_log2 = 12;                // LDS table slots of k_bucket_dedup (12: 32 KB, 13: 64 KB, 14: 128 KB)
+  int lds_log2 = 12;                // LDS table of k_bucket_dedup (11: 2048 slots, 12: 3072 = 24 KB, 13: 64 KB, 14: 128 KB)
   int64_t bytes = 0;
   std::vector<SlotHost> slots;
   std::vector<void*> allocs;
@@ -1995,8 +1995,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     delete s;
     return SPP_ERR_INVALID;
   }
-  // dedup geometry: <= ~1.5k distinct nodes per bucket at the worst case so that a 4096-slot LDS
-  // table (32 KB, 4-5 workgroups per CU) stays under 40 % load; larger tables only when the bucket
+  // dedup geometry: <= ~1.5k distinct nodes per bucket at the worst case so that a 3072-slot LDS
+  // table (24 KB, 6 workgroups per CU) stays at most half full; larger tables only when the bucket
   // count is capped
   static const int64_t bucket_nodes = [] {  // worst-case distinct nodes per bucket the geometry aims for
     const char* e = getenv("SPP_DEDUP_BUCKET");
@@ -2009,7 +2009,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   s->geom.nb = 1 << nb_log2;
   const int64_t per_bucket = (ucap + s->geom.nb - 1) / s->geom.nb;
   s->geom.kcap = (int32_t)std::min<int64_t>(per_bucket + per_bucket / 2 + 256, 0x7fffffff);
-  s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 2048 ? 13 : (per_bucket > 820 ? 12 : 11));
+  // tier 12 is a 3072-slot table (SPP_DEDUP_SLOTS12): at most 1536 distinct nodes per bucket in the worst case, half full
+  s->lds_log2 = per_bucket > 6144 ? 14 : (per_bucket > 1536 ? 13 : (per_bucket > 820 ? 12 : 11));
   for (int h = 0; h < H; ++h) {
     // as few buckets as keep the hop's worst-case node count per bucket within the LDS table's budget
     int c = std::max(0, nb_log2 - kMaxFineLog2);
@@ -2581,7 +2582,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
     // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
 #ifndef SPP_DEDUP_SLOTS12
-#define SPP_DEDUP_SLOTS12 4096
+#define SPP_DEDUP_SLOTS12 3072  // 24 KB: six workgroups per compute unit, a quarter less to clear per bucket (4096: +3.5 % lone chain)
 #endif
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
