@@ -1,8 +1,11 @@
-"""Which formulation of the SAGE layer-1 GEMMs does the library run fastest? (fp32, M=164k, K=256, N=256)"""
+"""Which formulation of the SAGE layer GEMMs does the library run fastest? (fp32; default M=164k, K=256, N=256 = layer 1;
+MKN=15333,512,256 = layer 2)"""
+import os
+
 import torch
 
 dev = torch.device("cuda", 0)
-M, K, N = 164_000, 256, 256
+M, K, N = (int(v) for v in os.environ.get("MKN", "164000,256,256").split(","))
 a = torch.randn(M, K, device=dev)
 w = torch.randn(N, K, device=dev)
 g = torch.randn(M, N, device=dev)
@@ -35,8 +38,10 @@ for parts in (2, 4, 8):
             torch.mm(a[i * c:(i + 1) * c], wt, out=out[i * c:(i + 1) * c])
     print(f"forward  {parts} row chunks (mm out=): %.1f us" % timeit(f))
 print("wgrad    g.t() @ a:            %.1f us" % timeit(lambda: g.t() @ a))
-for slabs in (16, 32, 64, 128, 256):
+for slabs in (2, 4, 8, 16, 32, 64, 128, 256):
     c = M // slabs
+    if c < 256:
+        continue
 
     def f():
         return torch.bmm(g[:slabs * c].view(slabs, c, N).transpose(1, 2), a[:slabs * c].view(slabs, c, K)).sum(0)
