@@ -562,6 +562,7 @@ def main():
     # (every window is in the line).
     R = a.windows if a.windows > 0 else max(6, 2 * -(-128 // max(1, a.steps)))
     xb0 = feeder.exchange_bytes()
+    dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
     if os.environ.get("SPP_BENCH_STALL_DUMP"):        # diagnostic: Python stacks of all threads every N seconds of the timed region
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["SPP_BENCH_STALL_DUMP"]), repeat=True)
@@ -596,6 +597,7 @@ def main():
         torch.cuda.synchronize()
         win.append((time.perf_counter() - t0, float(edges), float(nodes)))
     xb1 = feeder.exchange_bytes()
+    dev_allocs_timed = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0
     if os.environ.get("SPP_BENCH_STALL_DUMP"):
         faulthandler.cancel_dump_traceback_later()
     # gather-kernel time, measured live with HIP events on the launching stream
@@ -719,7 +721,8 @@ def main():
             "hbm": {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
                     "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
                     "torch_alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
-                    "torch_device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))},
+                    "torch_device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)),
+                    "torch_device_allocs_in_timed_region": dev_allocs_timed},   # hipMalloc calls of the caching allocator
             "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,

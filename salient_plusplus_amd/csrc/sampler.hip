@@ -1828,17 +1828,23 @@ struct Col32 {
   }
 };
 // Streams of the data path.  SPP_STREAM_PRIORITY=low puts them below the consumer's stream (torch's current stream has
-// the default priority): the dispatcher then hands the model step's kernels out first and the data path takes what is left
-static hipError_t create_data_stream(hipStream_t* st) {
-  static const int prio = [] {
-    const char* e = getenv("SPP_STREAM_PRIORITY");
+// the default priority): the dispatcher then hands the model step's kernels out first and the data path takes what is left.
+// SPP_SAMPLING_PRIORITY / SPP_DELIVERY_PRIORITY set the sampling streams / the delivery and exchange streams apart
+// (low | high | a number); unset = SPP_STREAM_PRIORITY = the default priority.
+static hipError_t create_data_stream(hipStream_t* st, bool sampling) {
+  auto parse = [](const char* name) -> int {
+    const char* e = getenv(name);
     if (!e || !*e) return 0;
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return 0;
     if (!strcmp(e, "low")) return least;
     if (!strcmp(e, "high")) return greatest;
     return atoi(e);
-  }();
+  };
+  static const int prio_all = parse("SPP_STREAM_PRIORITY");
+  static const int prio_s = getenv("SPP_SAMPLING_PRIORITY") ? parse("SPP_SAMPLING_PRIORITY") : prio_all;
+  static const int prio_d = getenv("SPP_DELIVERY_PRIORITY") ? parse("SPP_DELIVERY_PRIORITY") : prio_all;
+  const int prio = sampling ? prio_s : prio_d;
   return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
@@ -2233,7 +2239,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     }
   }
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
-  if (rc == SPP_OK && create_data_stream(&s->deliver_stream) != hipSuccess) {
+  if (rc == SPP_OK && create_data_stream(&s->deliver_stream, false) != hipSuccess) {
     set_error("spp_sampler_create: stream creation failed");
     rc = SPP_ERR_HIP;
   }
@@ -2362,7 +2368,7 @@ hipStream_t sampler_work_stream(spp_sampler* s, int i) {
     return v < 1 ? 1 : (v > kMaxWorkStreams ? kMaxWorkStreams : v);
   }();
   hipStream_t& st = s->work_streams[i % n_streams];
-  if (!st && create_data_stream(&st) != hipSuccess) st = nullptr;  // null stream as last resort
+  if (!st && create_data_stream(&st, true) != hipSuccess) st = nullptr;  // null stream as last resort
   return st;
 }
 
@@ -2886,7 +2892,7 @@ spp_status sampler_xbuf_counts(spp_sampler* s, XBuf* xb, int64_t bytes) {
 }
 
 hipStream_t sampler_comm_stream(spp_sampler* s) {
-  if (!s->comm_stream && create_data_stream(&s->comm_stream) != hipSuccess)
+  if (!s->comm_stream && create_data_stream(&s->comm_stream, false) != hipSuccess)
     s->comm_stream = nullptr;
   return s->comm_stream;
 }
