@@ -76,7 +76,8 @@ def parse():
                          "launcher's default) or on a 1/N slice of one global permutation")
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps run back to back, pipeline kept full in between; the "
-                         "reported ms_per_step / value are the MEAN over all windows (0 = max(6, 2 * ceil(128 / steps)))")
+                         "reported ms_per_step / value are the mean over the windows, without the slowest and the fastest "
+                         "one when there are 8 or more (0 = max(6, 2 * ceil(128 / steps)))")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -616,12 +617,18 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)                   # whole-job edges / nodes
         stats = torch.cat([tmax.unsqueeze(1), tot], dim=1)
     win = stats.cpu().tolist()
-    # reported: the MEAN window, i.e. the whole timed region / all its steps (value x steps x windows reproduces
-    # timed_region_s).  The median stays in the line: with K not a multiple of the sampler's group the windows differ by
-    # where their closing synchronize catches the refill chains (every 4th of the 20-step windows is ~25 % longer with
-    # groups of 16), and a median would simply leave those out.
-    dt, edges, nodes = (sum(w[j] for w in win) / R for j in range(3))
-    srt = sorted(w[0] for w in win)
+    # reported: the mean window -- the whole timed region / all its steps -- with ONE guard: with 8 or more windows the
+    # slowest and the fastest are left out (a trimmed mean).  The median stays in the line too: with K not a multiple of
+    # the sampler's group the windows differ by where their closing synchronize catches the refill chains (every 4th of
+    # the 20-step windows is ~25 % longer with groups of 16) and a median would simply leave all of those out; the plain
+    # mean, on the other hand, is at the mercy of one stall -- hipMalloc inside torch's caching allocator took 0.5 s
+    # once per S-mag process and 3.6 s in one S-papers run of ~45 (profiles/r03_ab_r6_priorities_allocs.txt), 400-28000
+    # steps' worth in a single step.  Every window is in the line, and so are the plain mean and the median.
+    order = sorted(range(R), key=lambda k: win[k][0])
+    kept = order[1:-1] if R >= 8 else order
+    dt, edges, nodes = (sum(win[k][j] for k in kept) / len(kept) for j in range(3))
+    dt_mean = sum(w[0] for w in win) / R
+    srt = [win[k][0] for k in order]
     dt_median = srt[R // 2] if R % 2 else 0.5 * (srt[R // 2 - 1] + srt[R // 2])
     window_ms = [w[0] / a.steps * 1e3 for w in win]
     timed_total_s = sum(w[0] for w in win)
@@ -712,9 +719,10 @@ def main():
             "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
                        "parallelism": parallelism, "slots_in_flight": a.slots},
-            "windows": {"n": R, "steps_each": a.steps, "reported": "mean over all windows (timed_region_s / all steps)",
+            "windows": {"n": R, "steps_each": a.steps, "reported": ("mean over the windows without the slowest and the fastest one" if R >= 8
+                                     else "mean over all windows (timed_region_s / all steps)"),
                         "ms_per_step_min": min(window_ms), "ms_per_step_median": dt_median / a.steps * 1e3,
-                        "ms_per_step_mean": dt / a.steps * 1e3,
+                        "ms_per_step_mean": dt_mean / a.steps * 1e3,
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
                         "ms_per_step_all": [round(v, 5) for v in window_ms]},
             "timed_region_s": timed_total_s,          # all R windows (also under "windows")

@@ -34,9 +34,14 @@ def _check_common(d, n_gpus):
     assert d["n_gpus"] == n_gpus and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
-    # the line describes its own timed region: value x steps x windows reproduces it
+    # the line describes its own timed region: the plain mean x steps x windows reproduces it, every window is listed,
+    # and the reported figure is that mean (fewer than 8 windows) or the mean without the slowest and the fastest window
     w = d["windows"]
-    assert abs(d["ms_per_step"] * 1e-3 * d["steps"] * w["n"] - d["timed_region_s"]) <= 1e-6 + 1e-3 * d["timed_region_s"]
+    assert abs(w["ms_per_step_mean"] * 1e-3 * d["steps"] * w["n"] - d["timed_region_s"]) <= 1e-6 + 1e-3 * d["timed_region_s"]
+    allw = sorted(w["ms_per_step_all"])
+    assert len(allw) == w["n"]
+    kept = allw[1:-1] if w["n"] >= 8 else allw
+    assert abs(d["ms_per_step"] - sum(kept) / len(kept)) <= 1e-4 * d["ms_per_step"] + 1e-5
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
