@@ -559,8 +559,8 @@ def main():
     # R windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides (the
     # closing bracket of a window is the opening bracket of the next, so the sampler's slots stay full
     # in between).  A single 20-step window is ~3 ms: its closing synchronize also waits for the refill
-    # chains the sampler has in flight, which makes one short window noisy.  Reported: the mean over all windows
-    # (every window is in the line).
+    # chains the sampler has in flight, which makes one short window noisy.  Reported: the mean over the windows (see
+    # below for the one guard); every window is in the line.
     R = a.windows if a.windows > 0 else max(6, 2 * -(-128 // max(1, a.steps)))
     xb0 = feeder.exchange_bytes()
     dev_allocs0 = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
