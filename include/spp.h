@@ -345,8 +345,13 @@ spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
  *   spp_session_export_group: writes the n batches returned by the last spp_session_next_group into caller
  *     buffers with one launch on `stream` (per batch as spp_session_export: MFG, x = x_src[n_id] or the rows
  *     assembled from the exchange, y = y_src[n_id[:stop-start]]), then recycles the group's slot-set.
- * The per-batch calls (spp_session_next / spp_session_export) and the group calls may be mixed only at group
- * boundaries. */
+ *   Fetch as a group, deliver one by one: instead of ONE spp_session_export_group the group returned by
+ *     spp_session_next_group may be exported member by member, in index order, by n calls of spp_session_export
+ *     (one launch each, on the stream given to each call; the slot-set is recycled after the last).  The caller
+ *     then sizes and allocates the outputs of all n batches at once and pays one export call per batch, while the
+ *     GPU sees the per-batch launches -- which measured faster than the single launch.  Once a
+ *     member has been exported this way spp_session_export_group is refused for that group.
+ * spp_session_next and the group calls may be mixed only at group boundaries. */
 typedef struct spp_group_out {
   spp_mfg_out mfg;                 /* as spp_session_export's mfg (pointers may be NULL = skip) */
   void* x_out;                     /* [U, x_row_bytes] dense, or NULL                           */

@@ -106,7 +106,8 @@ struct spp_session {
   std::string launch_err;
   int64_t next_to_deliver = 0;           // batch index
   int32_t current_slot = -1;             // delivered by next(), not yet exported/recycled
-  int64_t current_group = -1;            // delivered by next_group(), not yet exported
+  int64_t current_group = -1;            // delivered by next_group(), not yet (completely) exported
+  int32_t group_member = 0;              // its members exported so far by per-batch spp_session_export calls
   int32_t open_slot = -1;                // last slot exported without an event of its own (mid-group), and its stream
   hipStream_t open_stream = nullptr;
   int64_t blocked_us = 0;
@@ -869,12 +870,15 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
                                          const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,
                                          void* stream) {
   SPP_REQUIRE(s, "spp_session_export: NULL session");
-  if (s->current_slot < 0) {
-    set_error("spp_session_export: no current batch (call spp_session_next first)");
+  // Either the batch spp_session_next returned, or -- after spp_session_next_group -- the group's next member: the
+  // members of a fetched group may be exported one launch each, in order, instead of by one spp_session_export_group
+  const bool member = s->current_slot < 0 && s->current_group >= 0;
+  if (s->current_slot < 0 && !member) {
+    set_error("spp_session_export: no current batch (call spp_session_next or spp_session_next_group first)");
     return SPP_ERR_STATE;
   }
-  const int32_t slot = s->current_slot;
-  const int64_t b = s->next_to_deliver - 1;
+  const int64_t b = member ? s->current_group * s->G + s->group_member : s->next_to_deliver - 1;
+  const int32_t slot = member ? (int32_t)((s->current_group % s->num_sets) * s->G + s->group_member) : s->current_slot;
   const int64_t bs = (int64_t)s->ranges[(size_t)b].second - s->ranges[(size_t)b].first;
   (void)x_rows;
   (void)y_rows;
@@ -916,6 +920,15 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   } else {
     s->open_slot = slot;
     s->open_stream = st;
+  }
+  if (member) {
+    if (++s->group_member == group_len(s, s->current_group)) {
+      const int64_t g = s->current_group;
+      s->current_group = -1;
+      s->group_member = 0;
+      notify_group_consumed(s, g + 1);
+    }
+    return SPP_OK;
   }
   return retire_current(s);
 }
@@ -991,6 +1004,10 @@ extern "C" spp_status spp_session_export_group(spp_session* s, int32_t n, const 
   }
   const int64_t g = s->current_group;
   SPP_REQUIRE(n == group_len(s, g), "spp_session_export_group: the group holds %d batches, %d given", group_len(s, g), n);
+  if (s->group_member != 0) {
+    set_error("spp_session_export_group: %d members of the group have been exported one by one already", s->group_member);
+    return SPP_ERR_STATE;
+  }
   (void)x_rows;
   (void)y_rows;
   const int set = (int)(g % s->num_sets);

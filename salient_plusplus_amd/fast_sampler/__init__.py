@@ -587,6 +587,12 @@ class Session:
         # SLOWER than one launch per batch once that path's queue markers were trimmed (0.136 vs 0.133 ms per batch in
         # 192-step windows, 0.163 vs 0.146 in 20-step windows) -- for consumers that are host bound.
         self._group_mode = os.environ.get("SPP_GROUP_DELIVERY", "0") != "0"
+        # The default: the group is FETCHED as a whole (spp_session_next_group: one blocking call, three allocations and
+        # the views for all its batches) and delivered one launch per batch as the consumer asks (spp_session_export on
+        # the group's members) -- the host side of group delivery with the launches of batch-at-a-time delivery.
+        # SPP_GROUP_FETCH=0: spp_session_next / spp_session_export per batch, nine allocations each.
+        self._member_mode = not self._group_mode and os.environ.get("SPP_GROUP_FETCH", "1") != "0"
+        self._open = None                          # [next member, fetched group] while a group is partly handed out
         self._gdescs = (nat.BatchDesc * 16)()
         self._ready = collections.deque()          # (record, ready event, delivery stream) of delivered batches
         self._ended = False
@@ -639,13 +645,17 @@ class Session:
         self.close()
 
     def close(self):
+        # batches this object fetched or delivered ahead and never handed out do not count as consumed
+        opened = getattr(self, "_open", None)
+        unseen = len(getattr(self, "_ready", None) or ()) + (opened[1][0] - opened[0] if opened is not None else 0)
         if getattr(self, "_ready", None):
             self._ready.clear()
+        self._open = None
         if getattr(self, "_h", None) is not None:
             try:                # the counters outlive the native session (get_stats() after the last batch)
                 self._final = {
                     "total": int(self._L.spp_session_num_total_batches(self._h)),
-                    "consumed": int(self._L.spp_session_num_consumed_batches(self._h)),
+                    "consumed": int(self._L.spp_session_num_consumed_batches(self._h)) - unseen,
                     "group": int(self._L.spp_session_group_size(self._h)),
                     "blocked_us": int(self._L.spp_session_blocked_us(self._h)),
                     "blocked_n": int(self._L.spp_session_blocked_occasions(self._h)),
@@ -683,7 +693,11 @@ class Session:
     @property
     def num_consumed_batches(self) -> int:
         n = int(self._L.spp_session_num_consumed_batches(self._h)) if self._h is not None else self._final["consumed"]
-        return n - len(getattr(self, "_ready", ()))      # delivered to this object, not yet handed out
+        n -= len(getattr(self, "_ready", ()))            # delivered to this object, not yet handed out
+        opened = getattr(self, "_open", None)
+        if opened is not None:                           # fetched as a group, members not yet handed out
+            n -= opened[1][0] - opened[0]
+        return n
 
     @property
     def group_size(self) -> int:
@@ -772,18 +786,67 @@ class Session:
         """Deliver the next sampling group: one allocation per output kind (int64 MFG arena, feature rows, labels),
         ONE launch for all its batches, the records appended to self._ready.  False: not ready yet (block=False)
         or no group left."""
-        if self._h is None or self._ended:
+        grp = self._open_group(block)
+        if grp is None:
             return False
+        n, outs, records, xa, ya, flags = grp
+        dev = self._dev
+        distributed, native, count_remote, rank = flags
+        stream = torch.cuda.current_stream(dev)
+        nat.check(self._L.spp_session_export_group(self._h, n, outs, xa[0], xa[1], xa[2], xa[3], ya[0], ya[1], ya[2],
+                                                   C.c_void_p(stream.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for r in records:
+            self._ready.append((self._make_record(r, flags), ev, stream))
+        return True
+
+    def _make_record(self, r, flags):
+        (x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, U) = r
+        distributed, native, count_remote, rank = flags
+        if not distributed:
+            if x is None:
+                x = torch.empty((U, 0), device=self._dev)
+            return (x, y, adjs, rng)
+        return self._proto_record(x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank)
+
+    def _next_member(self, block: bool):
+        """The default delivery: the sampling group is FETCHED as a whole (one blocking call, one allocation per output
+        kind for all its batches, the views cut once) and its batches are then delivered one launch each, when asked
+        for -- the host work of a batch is one export call and the record, the GPU sees the same per-batch launches as
+        with batch-at-a-time calls."""
+        if self._open is None:
+            grp = self._open_group(block)
+            if grp is None:
+                return None
+            self._open = [0, grp]
+        i, (n, outs, records, xa, ya, flags) = self._open
+        o = outs[i]
+        stream = torch.cuda.current_stream(self._dev)
+        nat.check(self._L.spp_session_export(self._h, C.byref(o.mfg), xa[0], xa[1], xa[2], xa[3], o.x_out,
+                                             ya[0], ya[1], ya[2], o.y_out, C.c_void_p(stream.cuda_stream)))
+        rec = self._make_record(records[i], flags)
+        if i + 1 == n:
+            self._open = None
+        else:
+            self._open[0] = i + 1
+        return rec
+
+    def _open_group(self, block: bool):
+        """spp_session_next_group + the group's output arenas and views.  None: not ready yet (block=False) or no group
+        left; else (n, outs, records, x source args, y source args, (distributed, native, count_remote, rank))."""
+        if self._h is None or self._ended:
+            return None
         n_c = C.c_int32(0)
         rc = self._L.spp_session_next_group(self._h, 1 if block else 0, self._gdescs, C.byref(n_c))
         nat.check(rc)
         if rc == 2:
-            return False
+            return None
         if rc == 0:                                   # end of data: the sampler goes back to the pool once the queue is handed out
             self._ended = True
             if not self._ready:
                 self._finish()
-            return False
+            return None
         n = n_c.value
         dev = self._dev
         cfg = self.config
@@ -890,22 +953,9 @@ class Session:
                 o.y_out = (y_base + yo * yrow_b) if bss[i] else None
                 yo += bss[i]
             records.append((x, y, adjs, (start, stop), n_id, nids, flat, cached, perm, pc, U))
-        stream = torch.cuda.current_stream(dev)
         xa = self._x_args if (want_x and not native) else (None, 0, 0, 0)
         ya = self._y_args if want_y else (None, 0, 0)
-        nat.check(self._L.spp_session_export_group(self._h, n, outs, xa[0], xa[1], xa[2], xa[3], ya[0], ya[1], ya[2],
-                                                   C.c_void_p(stream.cuda_stream)))
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        for (x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, U) in records:
-            if not distributed:
-                if x is None:
-                    x = torch.empty((U, 0), device=dev)
-                rec = (x, y, adjs, rng)
-            else:
-                rec = self._proto_record(x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank)
-            self._ready.append((rec, ev, stream))
-        return True
+        return n, outs, records, xa, ya, (distributed, native, count_remote, rank)
 
     def _proto_record(self, x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank):
         b = ProtoDistributedBatch()
@@ -957,6 +1007,8 @@ class Session:
         (worker non-distributed branch, fast_sampler.cpp:1004-1016)."""
         if self._group_mode:
             return self._pop_ready(_block)
+        if self._member_mode:
+            return self._next_member(_block)
         if not self._next_desc(_block):
             return None
         d = self._desc
@@ -987,8 +1039,8 @@ class Session:
 
     def blocking_get_batch_distributed(self, _block=True):
         """-> None or ProtoDistributedBatch (worker distributed branch, fast_sampler.cpp:1017-1272)."""
-        if self._group_mode:
-            b = self._pop_ready(_block)
+        if self._group_mode or self._member_mode:
+            b = self._pop_ready(_block) if self._group_mode else self._next_member(_block)
             if b is not None and self.native_exchange and not self.compact_native_records:
                 # at most the two newest batches (double buffering); a consumer that never asks loses nothing
                 while len(self._native_feats) >= 2:

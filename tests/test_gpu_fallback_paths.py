@@ -12,7 +12,9 @@ of a short epoch with the oracle:
   * SPP_GROUP_DELIVERY=1 -- one delivery launch per sampling group instead of one per batch;
   * SPP_WHATIF_DUP=...   -- the measurement aid that launches the idempotent kernels twice changes nothing;
   * SPP_STREAM_PRIORITY=low, SPP_GROUP_SIZE=16 -- the data path's streams below the consumer's, the largest group;
-  * SPP_DEDUP_PREREAD=1  -- the dedup table is read before every compare-and-swap (the form until round 3)."""
+  * SPP_DEDUP_PREREAD=1  -- the dedup table is read before every compare-and-swap (the form until round 3);
+  * SPP_GROUP_FETCH=0    -- batch-at-a-time calls (spp_session_next / spp_session_export) instead of fetching the group
+                            as a whole and exporting its members one by one."""
 import os
 import subprocess
 import sys
@@ -75,6 +77,8 @@ print("CHILD_OK", n)
     {"SPP_RNG_ARENA_MB": "0", "SPP_GROUP_SIZE": "5", "SPP_XCD_AFFINITY": "0"},
     {"SPP_STREAM_PRIORITY": "low", "SPP_GROUP_SIZE": "16"},
     {"SPP_DEDUP_PREREAD": "1"},
+    {"SPP_GROUP_FETCH": "0"},
+    {"SPP_GROUP_FETCH": "0", "SPP_GROUP_SIZE": "3"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_chain_paths_are_bit_exact(env):
     e = dict(os.environ)

@@ -68,7 +68,8 @@ def test_group_path_equals_per_batch_path_and_the_oracle(fs, graph_a, sizes, bs,
 
 
 def test_group_and_batch_calls_mix_only_at_group_boundaries(fs, graph_a):
-    """straight through the C ABI: group 0 by next_group / export_group, group 1 batch by batch, group 2 grouped again"""
+    """straight through the C ABI: group 0 by next_group / export_group, group 1 batch by batch, group 2 fetched as a
+    group and exported member by member, group 3 grouped again, group 4 member by member"""
     from oracle import oracle as orc
     from salient_plusplus_amd import _native as nat
     L = nat.load()
@@ -122,6 +123,27 @@ def test_group_and_batch_calls_mix_only_at_group_boundaries(fs, graph_a):
         keep.append(bufs)
         return n.value
 
+    def members():
+        """fetch as a group, export member by member (one launch each)"""
+        assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == 1
+        k = n.value
+        for i in range(k):
+            U = int(descs[i].counts.num_nodes)
+            xs = torch.empty((U, x.size(1)), dtype=x.dtype, device=dev)
+            n_id = torch.empty(U, dtype=torch.int64, device=dev)
+            out = nat.MfgOut()
+            out.n_id = n_id.data_ptr()
+            nat.check(L.spp_session_export(h, C.byref(out), x.data_ptr(), x.size(0), row_b, 0, xs.data_ptr(), None, 0, 0, None, st))
+            check(descs[i], xs, n_id)
+            if i == 0 and k > 1:
+                # once a member went out on its own the single launch for the whole group is refused
+                outs = (nat.GroupOut * k)()
+                assert L.spp_session_export_group(h, k, outs, x.data_ptr(), x.size(0), row_b, 0, None, 0, 0, st) == -4
+                # ... and so is a per-batch fetch in the middle of the group
+                d1 = nat.BatchDesc()
+                assert L.spp_session_next(h, C.byref(d1)) == -4
+        return k
+
     def single():
         d = nat.BatchDesc()
         assert L.spp_session_next(h, C.byref(d)) == 1
@@ -140,9 +162,9 @@ def test_group_and_batch_calls_mix_only_at_group_boundaries(fs, graph_a):
         assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == -4
         for _ in range(3):
             single()
+        assert members() == 4
         assert grouped() == 4
-        assert grouped() == 4
-        assert grouped() == 4                              # 20 batches = 5 groups of 4
+        assert members() == 4                              # 20 batches = 5 groups of 4
         assert L.spp_session_next_group(h, 1, descs, C.byref(n)) == 0
         assert L.spp_session_num_consumed_batches(h) == nb
     finally:
