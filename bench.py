@@ -174,11 +174,19 @@ def model_step_timing(feeder, F, n_classes, steps=64, warm=16, windows=6, hip=Tr
                       " ".join(f"{v:.0f}" for v in host), file=sys.stderr, flush=True)
         return sum(out) / len(out), out
 
+    def n_dev_allocs():
+        return int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))
+
     fixed = feeder.next()
+    a0 = n_dev_allocs()
     m_only, w_only = run_windows(lambda: fixed, "resident batch")
+    a1 = n_dev_allocs()
     m_data, w_data = run_windows(feeder.next, "with data path")
+    a2 = n_dev_allocs()
     detail = {"windows": windows, "steps_each": steps, "warmup_steps": warm, "reported": "mean over all windows",
-              "model_only_ms_all": [round(v, 4) for v in w_only], "with_data_path_ms_all": [round(v, 4) for v in w_data]}
+              "model_only_ms_all": [round(v, 4) for v in w_only], "with_data_path_ms_all": [round(v, 4) for v in w_data],
+              # hipMalloc calls of torch's caching allocator during each leg (warm-up included)
+              "torch_device_allocs": {"resident_batch": a1 - a0, "with_data_path": a2 - a1}}
     return m_only, m_data, detail
 
 
