@@ -593,7 +593,7 @@ class Session:
         # SPP_GROUP_FETCH=0: spp_session_next / spp_session_export per batch, nine allocations each.
         self._member_mode = not self._group_mode and os.environ.get("SPP_GROUP_FETCH", "1") != "0"
         self._open = None                          # [next member, fetched group] while a group is partly handed out
-        self._gdescs = (nat.BatchDesc * 16)()
+        self._gdescs = (nat.BatchDesc * max(16, int(self._L.spp_session_group_size(self._h))))()   # one per batch of a group
         self._ready = collections.deque()          # (record, ready event, delivery stream) of delivered batches
         self._ended = False
         self.last_ready_event = None               # event after which the batch handed out last is complete
