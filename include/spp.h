@@ -54,7 +54,10 @@ int spp_device_count(void);
  * units (rows) of the TIMED launches of one kernel kind. */
 #define SPP_PROF_GATHER 0     /* k_gather_rows   (serial_index)              */
 #define SPP_PROF_ASSEMBLE 1   /* k_assemble      (distributed final assembly) */
-#define SPP_PROF_KINDS 2
+#define SPP_PROF_CHAIN 2      /* one sampling chain of a group of batches, first launch to last, on its sampling stream
+                                 (units = batches of the group; every chain is timed whatever n is: two events per
+                                 ~0.6 ms chain; sample_adj x hops, sample_cpu.hpp:25-143 / fast_sampler.cpp:191-227) */
+#define SPP_PROF_KINDS 3
 void spp_profile_enable(int on);
 spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
 

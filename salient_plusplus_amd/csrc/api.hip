@@ -23,7 +23,7 @@ static std::vector<ProfRec> g_prof[SPP_PROF_KINDS];
 int prof_begin(int kind, hipStream_t st, int64_t units) {
   if (!g_prof_on) return -1;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if ((g_prof_seen[kind]++ % g_prof_every) != 0) return -1;
+  if ((g_prof_seen[kind]++ % (kind == SPP_PROF_CHAIN ? 1 : g_prof_every)) != 0) return -1;
   if (g_prof[kind].size() >= (1u << 16)) return -1;
   ProfRec r{};
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;

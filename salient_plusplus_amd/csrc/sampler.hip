@@ -2500,6 +2500,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     return d;
   }();
   const DedupGeom geom = s->geom;
+  const int prof = prof_begin(SPP_PROF_CHAIN, st, n);
   // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
   SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
   const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
@@ -2635,6 +2636,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     hipLaunchKernelGGL(k_gpart_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), H, s->part);
     hipLaunchKernelGGL(k_gpart_scatter, dim3((gu) * gy), dim3(kNT), 0, st, s->d_slots, GG(gu), H, s->part, (int32_t)s->tcap[H]);
   }
+  prof_end(SPP_PROF_CHAIN, prof, st);
   SPP_HIP_TRY(hipGetLastError());
   SPP_HIP_TRY(hipMemcpyAsync(lead.host_state, lead.p.st, sizeof(SlotState) * (size_t)n, hipMemcpyDeviceToHost, st));
   SPP_HIP_TRY(hipEventRecord(lead.done, st));

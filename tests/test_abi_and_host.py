@@ -195,3 +195,38 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked_for():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_launcher_never_loads_the_gpu_runtime(tmp_path):
+    """The parent of `bench.py --gpus N`'s rank processes counts GPUs from the KFD topology in sysfs and is still free of
+    torch / libamdhip64 when it would spawn (--launch-dry-run reports /proc/self/maps instead of starting anything)."""
+    import json
+    import subprocess
+    import sys
+    topo = tmp_path / "nodes"
+    for k, props in enumerate(("cpu_cores_count 64\nsimd_count 0\n", "simd_count 1024\ndrm_render_minor 128\n",
+                               "simd_count 1024\ndrm_render_minor 129\n", "simd_count 1024\ndrm_render_minor 130\n")):
+        (topo / str(k)).mkdir(parents=True)
+        (topo / str(k) / "properties").write_text(props)
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    base["SPP_KFD_TOPOLOGY"] = str(topo)
+
+    def dry(gpus, **env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--launch-dry-run"],
+                           env=dict(base, **env), capture_output=True, text=True, timeout=60)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, (r.stdout, r.stderr[-500:])
+        return r.returncode, json.loads(lines[0]), r.stderr
+
+    rc, d, _ = dry(2)
+    assert rc == 0 and d["visible_gpus"] == 3 and d["ranks_wanted"] == 2            # the CPU node is not counted
+    assert d["torch_imported"] is False and d["libamdhip64_mapped"] is False and d["libhsa_runtime_mapped"] is False
+    rc, d, err = dry(4)
+    assert rc == 2 and "refusing to run fewer ranks" in err and d["libamdhip64_mapped"] is False
+    # the runtime's own narrowing is honoured: ROCR first, HIP among what is left; an empty list hides every GPU
+    assert dry(2, HIP_VISIBLE_DEVICES="0,2")[1]["visible_gpus"] == 2
+    assert dry(2, ROCR_VISIBLE_DEVICES="1,2", HIP_VISIBLE_DEVICES="1")[1]["visible_gpus"] == 1
+    assert dry(2, HIP_VISIBLE_DEVICES="0,7,1")[1]["visible_gpus"] == 1               # stops at the first index that does not exist
+    rc, d, _ = dry(2, HIP_VISIBLE_DEVICES="")
+    assert rc == 2 and d["visible_gpus"] == 0

@@ -2,7 +2,8 @@
 
 The single-GPU path and the partitioned path (RCCL communicator at world size 1, bucketing, native exchange, assembly, the
 model-step leg under DistributedDataParallel with consumer-issued exchanges) run as the driver runs them -- a child process,
-one JSON line on stdout -- on the small S-arxiv workload with a handful of steps."""
+one JSON line on stdout -- on the small S-arxiv workload with a handful of steps (two windows of 24: three sampling
+groups, so that the sampler's roofline entry has chains to time)."""
 import json
 import os
 import subprocess
@@ -18,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _run(extra):
     env = dict(os.environ)
     env.setdefault("MASTER_PORT", "29741")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "S-arxiv", "--steps", "6", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "S-arxiv", "--steps", "24", "--warmup", "2",
                         "--windows", "2", "--prime", "8", "--cpu-seconds", "1"] + extra, env=env, capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -31,22 +32,33 @@ def _check_common(d, n_gpus):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "timed_region_s"):
         assert k in d, k
-    assert d["n_gpus"] == n_gpus and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["n_gpus"] == n_gpus and d["steps"] == 24 and d["warmup"] == 2 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
-    # the line describes its own timed region: the plain mean x steps x windows reproduces it, every window is listed,
-    # and the reported figure is that mean (fewer than 8 windows) or the mean without the slowest and the fastest window
+    # the line describes its own timed region: the reported ms_per_step IS the plain mean, ms_per_step x steps x windows
+    # reproduces timed_region_s, every window is listed; the trimmed mean and the median are extra keys
     w = d["windows"]
-    assert abs(w["ms_per_step_mean"] * 1e-3 * d["steps"] * w["n"] - d["timed_region_s"]) <= 1e-6 + 1e-3 * d["timed_region_s"]
+    assert abs(d["ms_per_step"] * 1e-3 * d["steps"] * w["n"] - d["timed_region_s"]) <= 1e-6 + 1e-3 * d["timed_region_s"]
+    assert abs(w["ms_per_step_mean"] - d["ms_per_step"]) <= 1e-9
     allw = sorted(w["ms_per_step_all"])
     assert len(allw) == w["n"]
-    kept = allw[1:-1] if w["n"] >= 8 else allw
-    assert abs(d["ms_per_step"] - sum(kept) / len(kept)) <= 1e-4 * d["ms_per_step"] + 1e-5
+    assert abs(d["ms_per_step"] - sum(allw) / len(allw)) <= 1e-4 * d["ms_per_step"] + 1e-5
+    assert "ms_per_step_trimmed_mean" in w and "ms_per_step_median" in w
+    assert abs(d["value"] - d["sampled_edges_per_batch"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and 0 < roof["frac"] < 1
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the sampler's own roofline entry: algorithmic bytes of the run's batches over the chains' in-situ spans
+    rs = d["roofline_sampler"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_batch", "chain_span_ms_per_batch",
+              "chains_timed"):
+        assert k in rs, k
+    assert rs["bound"] == "hbm" and rs["unit"] == "GB/s" and 0 < rs["frac"] < 1 and rs["chains_timed"] >= 1
+    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9
+    # 24 T + 16 E + 8 dU per hop is at least 16 bytes per sampled edge
+    assert rs["algorithmic_bytes_per_batch"] >= 16 * d["sampled_edges_per_batch"]
 
 
 def test_single_gpu_line():
