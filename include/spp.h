@@ -396,7 +396,9 @@ spp_status spp_comm_unique_id(void* out_id /* SPP_COMM_ID_BYTES */);
  * (the copy PyTorch already loaded when there is one). */
 spp_status spp_comm_create(const void* id, int32_t rank, int32_t world, int32_t device, spp_comm** out);
 /* `world` communicators that live in ONE process and copy device-to-device (no RCCL): ranks are
- * driven by different host threads.  For single-GPU testing of the exchange logic only. */
+ * driven by different host threads.  A TEST AID compiled into the product library (the suite rehearses
+ * the exchange logic above the transport on one GPU with it): refused with SPP_ERR_INVALID unless the
+ * environment says SPP_ALLOW_LOCAL_COMM=1. */
 spp_status spp_comm_create_local(int32_t world, int32_t device, spp_comm** out /* [world] */);
 void spp_comm_destroy(spp_comm* c);
 int32_t spp_comm_rank(const spp_comm* c);

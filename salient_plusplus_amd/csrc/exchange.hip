@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -319,6 +320,12 @@ extern "C" spp_status spp_comm_create(const void* id, int32_t rank, int32_t worl
 
 extern "C" spp_status spp_comm_create_local(int32_t world, int32_t device, spp_comm** out) {
   SPP_REQUIRE(out && world >= 1 && world <= SPP_MAX_PARTS, "spp_comm_create_local: bad argument");
+  {  // a rehearsal transport, compiled into the product library for the test suite only: opt-in
+    const char* e = getenv("SPP_ALLOW_LOCAL_COMM");
+    SPP_REQUIRE(e && atoi(e) != 0,
+                "spp_comm_create_local: the in-process transport is a test aid (ranks as threads of one process on one "
+                "GPU); set SPP_ALLOW_LOCAL_COMM=1 to use it -- production ranks use spp_comm_create (RCCL)");
+  }
   SPP_REQUIRE(spp_device_count() > 0, "spp_comm_create_local: no HIP device available");
   SPP_HIP_TRY(hipSetDevice(device));
   auto w = std::make_shared<LocalWorld>();

@@ -11,6 +11,8 @@ WORKLOADS = {
     "S-tiny": (20_000, 200_000, 32, 4_096, [15, 10, 5], 256),
     "S-arxiv": (169_343, 1_166_243, 128, 90_941, [15, 10, 5], 1024),
     "S-products": (2_449_029, 61_859_140, 100, 196_615, [15, 10, 5], 1024),
+    # the same sizes with the planted 8-block locality of S-papers: the one-GPU rehearsal of the 8-rank exchange
+    "S-products-local": (2_449_029, 61_859_140, 100, 196_615, [15, 10, 5], 1024),
     # ogbn-papers100M scale: 111 M nodes, ~3.2 G symmetric nnz (col 25.8 GB int64), F=128 fp16 (28.4 GB)
     "S-papers": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
     "S-papers-uniform": (111_059_956, 1_615_685_872, 128, 1_207_179, [15, 10, 5], 1024),
@@ -27,7 +29,7 @@ WORKLOADS = {
 # drawn from the first endpoint's block with probability q (80 % intra-block edges = a 20 % edge cut
 # at 8 parts, less at 4 and 2 since the contiguous range partitions are unions of blocks).
 # "S-papers-uniform" is the same graph without it.  name -> (blocks, q)
-LOCALITY = {"S-papers": (8, 0.8), "S-mag": (8, 0.8)}
+LOCALITY = {"S-papers": (8, 0.8), "S-mag": (8, 0.8), "S-products-local": (8, 0.8)}
 
 
 MAX_KEYS_PER_SORT = 1 << 30     # torch.unique / CUB take fewer than 2^31 keys per call

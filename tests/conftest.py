@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the in-process transport (spp_comm_create_local: ranks as threads on one GPU) is a test aid the library refuses by default
+os.environ.setdefault("SPP_ALLOW_LOCAL_COMM", "1")
 
 
 def pytest_configure(config):

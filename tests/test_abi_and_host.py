@@ -78,6 +78,18 @@ def test_product_fails_loudly_without_gpu():
         mean_aggregate(torch.zeros(2, 4), torch.zeros(2, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 1)
 
 
+def test_local_transport_is_opt_in(monkeypatch):
+    """The in-process rehearsal transport ships inside the product library for the test suite only: without
+    SPP_ALLOW_LOCAL_COMM=1 (tests/conftest.py sets it) spp_comm_create_local refuses, with or without a GPU."""
+    import ctypes as C
+    from salient_plusplus_amd import _native as nat
+    monkeypatch.delenv("SPP_ALLOW_LOCAL_COMM", raising=False)
+    L = nat.load()
+    arr = (C.c_void_p * 2)()
+    assert L.spp_comm_create_local(2, 0, arr) == -1                      # SPP_ERR_INVALID, before any device is touched
+    assert b"SPP_ALLOW_LOCAL_COMM" in L.spp_last_error() and not arr[0]
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under salient_plusplus_amd/ may import, link or
     execute it (no CPU fallback on the product path)."""

@@ -385,3 +385,25 @@ def test_native_exchange_on_the_generic_sampling_path(monkeypatch):
         c.close()
     assert not errors, "\n".join(errors)
     assert not any(t.is_alive() for t in ts)
+
+
+def test_native_exchange_eight_ranks_headline_batches():
+    """The 8-GPU composition on one GPU: eight in-process ranks at S-products scale with the planted
+    8-block locality, batch 1024, federated seeds, analytic VIP cache of 10 % of N/P -- a third of every batch's ~750 k rows
+    arrives from seven peers.  Three sampling groups per rank and epoch (the 23 batches its own training vertices give), two epochs with different seed
+    orders (exchange buffers grown on the fly, then reused by the pooled sampler); every rank's x bit for bit
+    x_full[n_id] (tools/exchange_p8.py does the work and is also what the profile of this load runs)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SPP_ALLOW_LOCAL_COMM="1", VERIFY="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_p8.py"), "8", "24", "2"], env=env,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("EXCHANGE_P8 ")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0][len("EXCHANGE_P8 "):])
+    ranks = [ln for ln in r.stdout.splitlines() if ln.startswith("rank ")]
+    assert len(ranks) == 8 and all("bit exact True" in ln for ln in ranks), "\n".join(ranks)
+    assert d["P"] == 8 and d["batches_all_ranks"] >= 8 * 16 * 2 and d["batches_all_ranks"] % 16 == 0
+    assert d["rows_served"] == d["rows_fetched"] and d["rows_local"] + d["rows_cache"] + d["rows_fetched"] == d["rows_delivered"]
+    assert 0.15 < d["frac_fetched"] < 0.6 and d["frac_cache"] > 0.0        # a realistic remote fraction, cache in use

@@ -2,6 +2,7 @@
 size: a rehearsal of the N>1 pipeline (stalls, buffer growth), not a performance number -- the
 ranks share one GPU's HBM and one Python interpreter.  usage: bench_local_ranks.py [P] [batches]"""
 import os
+os.environ.setdefault("SPP_ALLOW_LOCAL_COMM", "1")   # rehearsal transport: opt-in
 import sys
 import threading
 import time
