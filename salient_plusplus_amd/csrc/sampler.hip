@@ -19,9 +19,9 @@
 //                                 (the last workgroup records E_h, #sampled); Floyd picks staged in LDS;
 //                                 col reads -> neighbour id of every edge position
 //                                 (k_hop_scan: single-workgroup scan instead, generic / very large hops)
-//   k_bucket_hist   tile/16k edges: edges per node-hash bucket; the last tile scans -> bucket offsets
 //   k_bucket_scatter tile/8k edges: tile bucket-sorted in LDS, (node, position) pairs written out as
-//                                 coalesced bucket runs; inv[p] = where edge p went
+//                                 coalesced runs into FIXED-CAPACITY bucket regions (no counting pass; what does
+//                                 not fit goes to an overflow list); inv[p] = where edge p went
 //   k_bucket_dedup  workgroup/bucket: LDS table of the bucket's known nodes + candidates ->
 //                                 per edge (bucket order): final local id, or T + earliest position of a new node
 //   k_hop_flag      4 edges/lane: results back to position order by reads (res[inv[p]]); bitmap of
@@ -85,14 +85,16 @@ constexpr int kMaxBuckets = 1 << kMaxBucketsLog2;
 constexpr int kMaxFineLog2 = 6;              // a hop's bucket spans at most 2^6 fine buckets
 constexpr int kMaxFinePerCoarse = 1 << kMaxFineLog2;
 constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile kernels (more waves per tile: latency bound)
-constexpr int kBucketTile = 16384;          // edges one workgroup partitions per pass (>= 4 per bucket and tile:
-                                            // one global atomic reserves room for several edges)
 constexpr int kScatterTile = 8192;           // edges k_bucket_scatter sorts in LDS per workgroup (48 KB + 8 B per bucket)
 constexpr int kScatterEPT = kScatterTile / kTileNT;
 static_assert(kScatterTile % kTileNT == 0 && kScatterTile <= 65536, "tile-local edge indices are 16 bit");
 constexpr int kDedupRegs = 6;                // pairs per thread k_bucket_dedup keeps in registers (6 x 256 edges per bucket)
-constexpr int kTileEPT = kBucketTile / kTileNT;  // edges per thread of a tile kernel
-static_assert(kBucketTile % kTileNT == 0, "a tile is a whole number of rounds");
+// Fixed-capacity bucket regions (round 4; a counting pass over the hop's edges used to size them exactly).  A hop
+// with edge capacity pcap and nbk buckets gives every bucket room for twice its share plus 64 pairs; what does not fit
+// (a hub reached by hundreds of edges of one hop) goes to an overflow list behind the regions, which only the
+// workgroups of the buckets that overflowed walk.  region_for(cap) bounds nbk * bcap for every hop geometry.
+__host__ __device__ inline int64_t region_for(int64_t edge_cap) { return 2 * edge_cap + 66 * (int64_t)(1 << 12); }
+static inline int32_t bucket_cap(int64_t pcap, int64_t nbk) { return (int32_t)((2 * pcap + nbk - 1) / nbk) + 64; }
 constexpr uint32_t kPending = 0x80000000u;  // known-list value = kPending | edge position of the previous hop
 
 // Workgroup -> (batch of the group, block within the batch).  Every grouped kernel is launched as a
@@ -168,9 +170,12 @@ struct SlotPtrs {
   int32_t* deg;
   int64_t* rowstart;
   int32_t* cval;       // neighbour node id of every edge position (later: local id, generic path)
-  unsigned long long* bpairs;  // edges regrouped by bucket: (node id << 32) | edge position
+  // edges regrouped by bucket: (node id << 32) | edge position.  Bucket b of a hop owns the fixed region
+  // [b * bcap, (b + 1) * bcap); pairs past a bucket's capacity live in the overflow list behind all regions, at
+  // [region, region + ovfc[h]) (region = region_for(edge capacity): the same for every hop)
+  unsigned long long* bpairs;
   uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order)
-  uint32_t* res;       // table value of every edge, in bucket order (k_bucket_dedup)
+  uint32_t* res;       // table value of every edge, indexed like bpairs (k_bucket_dedup)
   uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
   // first occurrences of the hop (new nodes), by edge position: per 64 positions one 16-byte record
   // {bitmap word, set bits in the earlier words of the same 256-position block}, plus the exclusive
@@ -180,9 +185,9 @@ struct SlotPtrs {
   int32_t* fsum;
   unsigned long long* known;   // [nb][kcap] known nodes per bucket: (node id << 32) | local id (or kPending | pos)
   int32_t* kcount;     // [nb] entries in each known list
-  int32_t* bcount;     // [nb] edges per bucket of the current hop (zero between hops)
-  int32_t* boff;       // [nb+1] exclusive offsets of the buckets in bpairs
-  int32_t* bcur;       // [nb] scatter cursors
+  int32_t* bfill;      // [nb] pairs each bucket received in the current hop, overflowed ones included (zero between
+                       // hops: the bucket's k_bucket_dedup workgroup resets it)
+  int32_t* ovfc;       // [SPP_MAX_HOPS] pairs of hop h that did not fit their bucket's region (zeroed per chain)
   uint32_t* rng[2];    // draws rng_skip .. of the batch stream (ping-pong: generated one group ahead)
   int32_t* bsum0;
   int32_t* bsum1;
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(kNT) void k_seed_init(const SlotPtrs* __restrict__ 
 // vmcnt(0)), take a ticket from a device-scope counter, and the workgroup that draws the last ticket
 // reads the partials back with agent-scope atomic loads and finishes the job: the placement-independent
 // 8-byte-granule hand-off of cdna_hip_programming.md G16 (atomics on both sides).  Only used where few
-// workgroups take tickets (k_bucket_hist: one per 16k edges): with one ticket per 256 elements the
+// workgroups take tickets (one per 1024 elements, k_hop_flag): with one ticket per 256 elements the
 // same-address atomics and their round trip made k_hop_count / k_hop_flag slower than a separate
 // single-workgroup scan launch (measured: sampling alone 76 -> 113 us/batch), so those keep k_hop_scan*.
 __device__ __forceinline__ int32_t acquire_i32(const int32_t* p) {
@@ -885,61 +890,6 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // ----------------------------------------------------------------------------------------------
 // dedup: regroup the hop's edges by bucket, then one workgroup per bucket with an LDS table
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
-                                                      int32_t cb_log2, int64_t pcap, uint32_t idmask) {
-  SPP_GROUP_BLOCK(gg);
-  __shared__ int32_t lh[kMaxBuckets];
-  __shared__ int32_t lscan[kTileNT / kWave + 1];
-  __shared__ int is_last;
-  const SlotPtrs& s = slots[gg.first_slot + by_];
-  const SPP_GLOBAL SlotState* st = G(s.st);
-  const SPP_GLOBAL int32_t* cval = G(s.cval);
-  const int32_t nbk = 1 << cb_log2;  // buckets of THIS hop (coarser than the known lists for small hops)
-  const int64_t base = (int64_t)bx_ * kBucketTile;
-  // one round trip: the state words and the tile's node ids (index clamped: E is not known yet; every
-  // load issued before the first use -- kTileEPT independent misses per lane)
-  const int32_t err0 = st->error;
-  const int32_t E0 = st->E[h];
-  int32_t v[kTileEPT];
-#pragma unroll
-  for (int u = 0; u < kTileEPT; ++u) {
-    const int64_t p = base + u * kTileNT + threadIdx.x;
-    v[u] = cval[p < pcap ? p : pcap - 1];
-  }
-  const int32_t E = err0 ? 0 : E0;
-  if (base >= E && bx_ != 0) return;  // tile 0 always takes part (E may be 0)
-  const int32_t ntiles = (int32_t)(((int64_t)E + kBucketTile - 1) / kBucketTile);
-  for (int b = threadIdx.x; b < nbk; b += kTileNT) lh[b] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < kTileEPT; ++u)  // (entries may carry a degree tag above the id bits: validity is the position's)
-    if (base + u * kTileNT + threadIdx.x < E) atomicAdd(&lh[bucket_of((uint32_t)v[u] & idmask, cb_log2)], 1);
-  __syncthreads();
-  for (int b = threadIdx.x; b < nbk; b += kTileNT)
-    if (lh[b]) atomicAdd(&s.bcount[b], lh[b]);  // device-scope atomics: coherent without a fence
-  // last tile: exclusive scan of the bucket counts -> offsets and scatter cursors; counts re-zeroed
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own atomics before the barrier
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = take_ticket_is_last(s.ctr, ntiles > 0 ? ntiles : 1) ? 1 : 0;
-  __syncthreads();
-  if (!is_last) return;
-  int32_t carry = 0;
-  for (int32_t bb = 0; bb < nbk; bb += kTileNT) {
-    const int32_t b = bb + threadIdx.x;
-    const int32_t v = (b < nbk) ? acquire_i32(&s.bcount[b]) : 0;
-    int32_t tot;
-    const int32_t ex = block_exclusive_scan<int32_t, kTileNT>(v, lscan, &tot);
-    if (b < nbk) {
-      s.boff[b] = carry + ex;
-      s.bcur[b] = carry + ex;
-      s.bcount[b] = 0;
-    }
-    carry += tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) s.boff[nbk] = carry;
-}
-
 // Regroups a tile of kScatterTile edges by bucket.  Scattered 8-byte stores leave the L2 as one
 // 32-byte write EACH (plain stores are written through; stores of different waves are never merged:
 // measured 26 B of fabric writes per 8-byte pair), and a million small random writes per batch are what
@@ -947,20 +897,24 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_hist(const SlotPtrs* __restr
 // then written out in bucket order: consecutive lanes store consecutive pairs of one bucket's run.
 // inv[p] (where edge p went) is stored in position order -- also coalesced -- so that the per-edge
 // results of k_bucket_dedup can stay in bucket order and be fetched back by reads (k_hop_flag).
+// Round 4: no counting pass ahead of it.  Bucket b owns the fixed region [b * bcap, (b + 1) * bcap) of bpairs; a
+// tile reserves room for its run with one atomic on the bucket's fill count; pairs that land past the region's end go
+// to the overflow list at [region, ...) one by one (rare: a node reached by hundreds of edges of one hop).
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                         int32_t h, int32_t cb_log2, int64_t pcap, uint32_t idmask) {
+                                                         int32_t h, int32_t cb_log2, int32_t bcap, int32_t region,
+                                                         int64_t pcap, uint32_t idmask) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t sc_lds[];
   const int32_t nbk = 1 << cb_log2;
   int32_t* cur = sc_lds;                // [nbk] tile histogram -> running slot cursor of each bucket
-  int32_t* delta = sc_lds + nbk;        // [nbk] (start of the tile's reservation in the bucket) - (first slot of the bucket)
+  int32_t* delta = sc_lds + nbk;        // [nbk] (position inside the bucket's region of the tile's first pair) - (its staging slot)
   uint32_t* snode = reinterpret_cast<uint32_t*>(sc_lds + 2 * nbk);               // [kScatterTile] node ids in bucket order
   uint16_t* sidx = reinterpret_cast<uint16_t*>(sc_lds + 2 * nbk + kScatterTile);  // [kScatterTile] tile-local edge index
   __shared__ int32_t lscan[kTileNT / kWave + 1];
   const SlotPtrs& s = slots[gg.first_slot + by_];
   const SPP_GLOBAL SlotState* st = G(s.st);
   const SPP_GLOBAL int32_t* cval = G(s.cval);
-  SPP_GLOBAL int32_t* bcur = G(s.bcur);
+  SPP_GLOBAL int32_t* bfill = G(s.bfill);
   SPP_GLOBAL uint32_t* inv = G(s.inv);
   SPP_GLOBAL unsigned long long* bpairs = G(s.bpairs);
   const int64_t base = (int64_t)bx_ * kScatterTile;
@@ -1002,7 +956,7 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
 #pragma unroll
     for (int k = 0; k < kMaxBuckets / kTileNT; ++k) {
       if (k < per && b0 + k < nbk) {  // (usually per == 1: one reservation per thread)
-        const int32_t g = c[k] ? __hip_atomic_fetch_add(bcur + b0 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int32_t g = c[k] ? __hip_atomic_fetch_add(bfill + b0 + k, c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         cur[b0 + k] = off;
         delta[b0 + k] = g - off;
         off += c[k];
@@ -1019,14 +973,22 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     const int32_t li = u * kTileNT + threadIdx.x;
     snode[slot] = c;
     sidx[slot] = (uint16_t)li;
-    inv[base + li] = (uint32_t)(slot + delta[b]);
+    const int32_t rel = slot + delta[b];  // position inside bucket b's region
+    if (rel < bcap) {
+      inv[base + li] = (uint32_t)((int32_t)b * bcap + rel);
+    } else {  // the bucket's region is full: the overflow list (one atomic per such pair; rare)
+      const int32_t j = __hip_atomic_fetch_add(G(s.ovfc) + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      inv[base + li] = (uint32_t)(region + j);
+      bpairs[(int64_t)region + j] = ((unsigned long long)c << 32) | (uint32_t)(base + li);
+    }
   }
   __syncthreads();
   const int32_t n_tile = (int32_t)((E - base) < kScatterTile ? (E - base) : kScatterTile);
   for (int k = threadIdx.x; k < n_tile; k += kTileNT) {
     const uint32_t c = snode[k];
-    const int32_t dst = k + delta[bucket_of(c, cb_log2)];
-    bpairs[dst] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
+    const int32_t b = (int32_t)bucket_of(c, cb_log2);
+    const int32_t rel = k + delta[b];
+    if (rel < bcap) bpairs[(int64_t)b * bcap + rel] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
   }
 }
 
@@ -1044,10 +1006,18 @@ __device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
 //   value = T + p      : p is the earliest edge position of this hop reaching the node
 // Every edge gets the final value of its node (evals[p]); the earliest edge of every new node appends
 // (node, kPending | p) to the bucket's known list for the later hops.
+// (amdgpu_waves_per_eu(6): 80 registers, six workgroups of four wavefronts per compute unit -- what the 24 KB table admits;
+// at 81 registers the kernel drops to five and the hop's launch takes 10-60 % longer)
+// amdgpu_waves_per_eu(6) for the small tables: 80 registers = six workgroups of four wavefronts per compute unit, what
+// a 24 KB table admits; the allocator lands on 81 otherwise (five: the hop's launch then takes 10-60 % longer) and
+// meets 80 with one 8-byte spill in the prologue.
 template <int NS>
-__global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
-                                                       int32_t h, DedupGeom g, int32_t cb_log2, int32_t hop_flags) {
+__global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 ? 6 : 1))) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
+                                                       int32_t hop_word, DedupGeom g, int32_t bcap, int32_t region) {
   SPP_GROUP_BLOCK(gg);
+  // hop_word = h | cb_log2 << 8 | hop_flags << 16 (one scalar register instead of three: the kernel is at the edge of
+  // both register files, and a spilled scalar costs a vector register -- 81 of them are five waves per SIMD instead of six)
+  const int32_t h = hop_word & 0xff, cb_log2 = (hop_word >> 8) & 0xff, hop_flags = hop_word >> 16;
   const int32_t last_hop = hop_flags & 1;    // no later hop: the known lists are not extended
   const bool no_preread = hop_flags & 2;     // candidates go straight to the compare-and-swap (mostly new keys)
   __shared__ unsigned long long tab[NS];
@@ -1073,7 +1043,13 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   const int32_t err0 = st->error;
   const uint32_t T = (uint32_t)st->cnt[h];
   const uint32_t Tprev = h > 0 ? (uint32_t)st->cnt[h - 1] : 0u;
-  const int32_t e0 = G(s.boff)[b], e1 = G(s.boff)[b + 1];
+  // the bucket's pairs: the first min(fill, bcap) entries of its region, plus -- when it overflowed -- its share of
+  // the hop's overflow list (walked by this workgroup alone)
+  // (workgroup-uniform values loaded through per-slot pointers arrive in vector registers: moved to scalar ones, the
+  // kernel sits exactly at the 80 registers six waves per SIMD allow)
+  const int32_t fill = __builtin_amdgcn_readfirstlane(G(s.bfill)[b]);
+  const int32_t e0 = b * bcap, e1 = e0 + (fill < bcap ? fill : bcap);
+  const bool spill = fill > bcap;  // block-uniform
   for (int i = threadIdx.x; i < nf; i += kNT) {
     fkc[i] = kcount[fb0 + i];
     fnew[i] = 0;
@@ -1168,6 +1144,13 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
     for (int u = 0; u < 4; ++u)
       if (q[u] != kEmptySlot) lds_upsert<false, NS, false>(tab, (uint32_t)(q[u] >> 32), T + (uint32_t)q[u], &ovf);
   }
+  if (spill) {  // this bucket's pairs in the overflow list
+    const int32_t n_ovf = G(s.ovfc)[h];
+    for (int i = threadIdx.x; i < n_ovf; i += kNT) {
+      const unsigned long long q = bpairs[(int64_t)region + i];
+      if ((int32_t)bucket_of((uint32_t)(q >> 32), cb_log2) == b) lds_upsert<false, NS, false>(tab, (uint32_t)(q >> 32), T + (uint32_t)q, &ovf);
+    }
+  }
   __syncthreads();
   if (ovf) {
     if (threadIdx.x == 0) atomicOr(&s.st->error, kErrBucketCap);
@@ -1188,7 +1171,15 @@ __global__ __launch_bounds__(kNT) void k_bucket_dedup(const SlotPtrs* __restrict
   for (int u = 0; u < kDedupRegs; ++u)
     if (pr[u] != kEmptySlot) resolve(pr[u], e0 + u * kNT + threadIdx.x);
   for (int i = e0 + kDedupRegs * kNT + threadIdx.x; i < e1; i += kNT) resolve(bpairs[i], i);
+  if (spill) {
+    const int32_t n_ovf = G(s.ovfc)[h];
+    for (int i = threadIdx.x; i < n_ovf; i += kNT) {
+      const unsigned long long q = bpairs[(int64_t)region + i];
+      if ((int32_t)bucket_of((uint32_t)(q >> 32), cb_log2) == b) resolve(q, region + i);
+    }
+  }
   __syncthreads();
+  if (threadIdx.x == 0) G(s.bfill)[b] = 0;  // the next hop's scatter counts from zero again
   if (threadIdx.x == 0 && ovf) atomicOr(&s.st->error, kErrBucketCap);
   for (int i = threadIdx.x; i < nf; i += kNT) {
     const int32_t room = g.kcap - fkc[i];
@@ -1899,7 +1890,8 @@ struct spp_sampler {
   SlotPtrs* d_slots = nullptr;       // device copy of every slot's pointer record
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
-  int32_t* counts = nullptr;         // [slot][2*nb+1]: kcount, bcount, ticket counter (zeroed per batch, one memset)
+  int32_t* counts = nullptr;         // [slot][counts_per_slot]: kcount, bfill, ticket counter, ovfc (zeroed per batch, one memset)
+  int64_t counts_per_slot = 0;       // 2 * nb + 1 + SPP_MAX_HOPS
   std::shared_ptr<Col32> col32_owner;  // int32 copy of cfg.col_dev, shared by the samplers of one graph
   int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
   std::shared_ptr<RowStubs> stubs_owner;
@@ -1996,7 +1988,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     etmp = std::max(etmp, s->ecap[h]);
   }
   const int64_t ucap = s->tcap[H];
-  if (ucap + etmp >= (1ll << 31)) {
+  if (ucap + etmp >= (1ll << 31) || region_for(etmp) + etmp >= (1ll << 31)) {
     set_error("spp_sampler_create: batch too large for 32-bit positions");
     delete s;
     return SPP_ERR_INVALID;
@@ -2048,10 +2040,11 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     rc = dev_alloc(s, &v, sizeof(SlotState) * (size_t)nslots);
     s->d_states = static_cast<SlotState*>(v);
   }
+  s->counts_per_slot = 2 * (int64_t)nb + 1 + SPP_MAX_HOPS;
   if (rc == SPP_OK) {
-    rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)(2 * nb + 1) * (size_t)nslots);
+    rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)s->counts_per_slot * (size_t)nslots);
     s->counts = static_cast<int32_t*>(v);
-    if (rc == SPP_OK && hipMemset(s->counts, 0, sizeof(int32_t) * (size_t)(2 * nb + 1) * (size_t)nslots) != hipSuccess) {
+    if (rc == SPP_OK && hipMemset(s->counts, 0, sizeof(int32_t) * (size_t)s->counts_per_slot * (size_t)nslots) != hipSuccess) {
       set_error("spp_sampler_create: hipMemset failed");
       rc = SPP_ERR_HIP;
     }
@@ -2079,8 +2072,6 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     A(p.bsum0, int32_t, nblk_max);
     A(p.bsum1, int32_t, nblk_max);
     A(p.known, unsigned long long, (int64_t)nb * s->geom.kcap);
-    A(p.boff, int32_t, nb + 1);
-    A(p.bcur, int32_t, nb);
     for (int h = 0; h < H; ++h) {
       A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
       A(p.out_col[h], int32_t, s->ecap[h]);
@@ -2095,26 +2086,28 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       A(p.pblk, int32_t, (int64_t)(s->part.P + 1) * s->part.nblk_cap);
     }
 #undef A
-    p.kcount = s->counts + (size_t)i * (2 * nb + 1);
-    p.bcount = p.kcount + nb;
-    p.ctr = p.bcount + nb;
+    p.kcount = s->counts + (size_t)i * (size_t)s->counts_per_slot;
+    p.bfill = p.kcount + nb;
+    p.ctr = p.bfill + nb;
+    p.ovfc = p.ctr + 1;
     p.st = s->d_states + i;
     sl.host_state = s->h_states + i;
     // per-edge temporaries are separately allocated so the generic path can grow them
     if (rc == SPP_OK) {
       sl.etmp_cap = etmp;
       hipError_t e = hipMalloc((void**)&p.cval, sizeof(int32_t) * (size_t)etmp);
-      if (e == hipSuccess) e = hipMalloc((void**)&p.bpairs, sizeof(unsigned long long) * (size_t)etmp);
+      const size_t n_bucketed = (size_t)(region_for(etmp) + etmp);  // fixed-capacity bucket regions + overflow list
+      if (e == hipSuccess) e = hipMalloc((void**)&p.bpairs, sizeof(unsigned long long) * n_bucketed);
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.inv, sizeof(uint32_t) * (size_t)etmp);
-      if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * n_bucketed);
       if (e == hipSuccess) e = hipMalloc((void**)&p.fwords, rank_bytes(etmp));
       if (e == hipSuccess) p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p.fwords) + rank_off_fsum(etmp));
       if (e != hipSuccess) {
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
       }
-      s->bytes += 24 * etmp + (int64_t)rank_bytes(etmp);
+      s->bytes += 12 * etmp + 12 * (int64_t)n_bucketed + (int64_t)rank_bytes(etmp);
     }
     if (rc == SPP_OK && (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&sl.exported, hipEventDisableTiming) != hipSuccess)) {
@@ -2330,16 +2323,18 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
     sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.fwords = nullptr;
     sl.p.inv = nullptr; sl.p.res = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * (size_t)cap));
+    SPP_REQUIRE(region_for(cap) + cap < (1ll << 31), "spp_sampler: a hop of %lld edges exceeds 32-bit bucket positions", (long long)need);
+    const size_t n_bucketed = (size_t)(region_for(cap) + cap);
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * n_bucketed));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.inv, sizeof(uint32_t) * (size_t)cap));
-    SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * n_bucketed));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.fwords, rank_bytes(cap)));
     sl.p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sl.p.fwords) + rank_off_fsum(cap));
     SPP_HIP_TRY(hipMemcpy(sl.p.fwords, old_fwords, 16 * (size_t)rank_words(old_cap), hipMemcpyDeviceToDevice));
     SPP_HIP_TRY(hipMemcpy(sl.p.fsum, old_fsum, 4 * (size_t)rank_blocks(old_cap), hipMemcpyDeviceToDevice));
     (void)hipFree(old_fwords);
-    s->bytes += 24 * (cap - sl.etmp_cap) + (int64_t)rank_bytes(cap) - (int64_t)rank_bytes(sl.etmp_cap);
+    s->bytes += 48 * (cap - sl.etmp_cap) + (int64_t)rank_bytes(cap) - (int64_t)rank_bytes(sl.etmp_cap);
     sl.etmp_cap = cap;
     changed = true;
   }
@@ -2488,12 +2483,11 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 
   // Measurement aid (tools/ab_env.sh): SPP_WHATIF_DUP=count,pick,tiles,flag,rows launches the named (idempotent)
   // kernels twice, so that the step time's increase is that kernel's cost IN SITU.  Results are unchanged.
-  static const struct Dup { int count, pick, tiles, flag, rows; } dup = [] {
-    Dup d{1, 1, 1, 1, 1};
+  static const struct Dup { int count, pick, flag, rows; } dup = [] {
+    Dup d{1, 1, 1, 1};
     if (const char* e = getenv("SPP_WHATIF_DUP")) {
       if (strstr(e, "count")) d.count = 2;
       if (strstr(e, "pick")) d.pick = 2;
-      if (strstr(e, "tiles")) d.tiles = 2;
       if (strstr(e, "flag")) d.flag = 2;
       if (strstr(e, "rows")) d.rows = 2;
     }
@@ -2502,7 +2496,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   const DedupGeom geom = s->geom;
   const int prof = prof_begin(SPP_PROF_CHAIN, st, n);
   // empty known lists / bucket counters of the group's slots (contiguous): 8*nb bytes per batch
-  SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)(2 * geom.nb + 1) * (size_t)n, st));
+  SPP_HIP_TRY(hipMemsetAsync(lead.p.kcount, 0, sizeof(int32_t) * (size_t)s->counts_per_slot * (size_t)n, st));
   const unsigned gseed = (unsigned)ceil_div(max_seeds, kNT);
   ga.grid = GG(gseed);
   hipLaunchKernelGGL(k_seed_init, dim3(gseed * gy), dim3(kNT), 0, st, s->d_slots, ga, geom, rowptr, stubs,
@@ -2566,8 +2560,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
         hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col,
                            h, f, replace, idmask);
     }
-    // dedup: bucket histogram -> offsets -> regroup -> one workgroup per bucket with an LDS table
-    const unsigned gtile = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kBucketTile));
+    // dedup: regroup into fixed-capacity bucket regions -> one workgroup per bucket with an LDS table
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
     // bit 0: the known lists are not read after the last hop; bit 1: the candidates skip the table pre-read (most edges of
@@ -2577,14 +2570,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       return e && atoi(e) != 0;
     }();
     const int32_t last = ((h == H - 1) ? 1 : 0) | (!dedup_preread ? 2 : 0);
+    const int32_t hop_word = h | (s->cb_log2[h] << 8) | (last << 16);
     // positions < pcap are inside the per-edge scratch arrays whatever E turns out to be
     const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? lead.host_state->E[h] : s->ecap[h]);
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
-    for (int rep = 0; rep < dup.tiles; ++rep) {  // (the histogram resets the cursors the scatter advanced: the pair is idempotent)
-      hipLaunchKernelGGL(k_bucket_hist, dim3((gtile) * gy), dim3(kTileNT), 0, st, s->d_slots, GG(gtile), h, cb, pcap, idmask);
-      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, pcap, idmask);
-    }
+    const int32_t bcap = bucket_cap(pcap, nbk);                     // pairs a bucket's region holds
+    const int32_t region = (int32_t)region_for(lead.etmp_cap);       // first position of the overflow list
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, bcap, region, pcap, idmask);
     // LDS table of k_bucket_dedup: 2048 / 4096 / 8192 / 16384 slots (any size works: multiply-shift slot index).
     // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
     // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
@@ -2592,13 +2585,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
 #define SPP_DEDUP_SLOTS12 3072  // 24 KB: six workgroups per compute unit, a quarter less to clear per bucket (4096: +3.5 % lone chain)
 #endif
     if (s->lds_log2 == 11)
-      hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 13)
-      hipLaunchKernelGGL(k_bucket_dedup<8192>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<8192>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else
-      hipLaunchKernelGGL(k_bucket_dedup<16384>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), h, geom, cb, last);
+      hipLaunchKernelGGL(k_bucket_dedup<16384>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
     for (int rep = 0; rep < dup.flag; ++rep)
       hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,

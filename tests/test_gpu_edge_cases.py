@@ -157,3 +157,23 @@ def test_capacity_error_is_reported_not_silent(fs):
     assert b"max_batch" in L.spp_last_error()
     assert L.spp_sampler_sample(h, 5, C.c_void_p(seeds.data_ptr()), 2, 1, 0, None) < 0
     L.spp_sampler_destroy(h)
+
+
+@pytest.mark.parametrize("sizes,bs", [([15, 10, 5], 512), ([4, 4], 1024), ([20, 20, 20], 256)])
+def test_one_node_reached_by_thousands_of_edges_of_a_hop(fs, sizes, bs):
+    """Fixed-capacity bucket regions (round 4): every vertex lists vertex 7 among its few neighbours, so one dedup
+    bucket receives thousands of pairs per hop -- far past its region -- and the overflow list carries them; a second
+    family of hubs (ids = 0 mod 97) spreads more overflow over several buckets.  Bit-exact against the oracle."""
+    n = 40_000
+    rng = np.random.default_rng(11)
+    deg = rng.integers(3, 9, n).astype(np.int64)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n, rowptr[-1]).astype(np.int64)
+    col[rowptr[:-1]] = 7                                        # first neighbour of everyone
+    second = rowptr[:-1] + 1
+    col[second] = (rng.integers(0, n // 97, n) * 97)            # second neighbour: one of ~400 hubs
+    idx = rng.permutation(n)[:2 * bs]
+    b = run_session(fs, rowptr, col, idx, sizes, bs)
+    assert len(b) == 2
+    check_against_oracle(b, rowptr, col, idx, sizes)
