@@ -61,6 +61,11 @@ int spp_device_count(void);
 void spp_profile_enable(int on);
 spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
 
+/* Run-time tuning knobs (measurement aid and the hook of embedders that pace the data path themselves).
+ * "gather_wg_per_cu": workgroups per compute unit a row gather / delivery launch may put on the chip (default 16, or
+ * SPP_GATHER_WG_PER_CU); value <= 0 only reads.  Returns the previous value, or a negative spp_status. */
+int spp_tune(const char* key, int value);
+
 /* Asynchronously detected data errors.  The reference's CPU code does not range-check row indices
  * (fast_sampler.cpp:253-256 copies in[idx[i]] blindly); here a kernel that meets an index outside
  * its table clamps it to a valid row (no fault) and raises a bit in a per-device word in pinned host

@@ -73,6 +73,7 @@ SIGNATURES = {
     "spp_device_count": (C.c_int, []),
     "spp_async_errors": (C.c_int, [C.c_int, C.c_int]),
     "spp_profile_enable": (None, [C.c_int]),
+    "spp_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "spp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
     "spp_mt19937_fill": (C.c_int, [u32, i64, i64, p, p]),
     "spp_batch_seed": (u32, [i32]),

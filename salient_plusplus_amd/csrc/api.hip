@@ -1,8 +1,10 @@
 // libspp_hip.so: error plumbing + trivial entry points of include/spp.h.
 #include "spp_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -37,6 +39,19 @@ void prof_end(int kind, int idx, hipStream_t st) {
   if (idx < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (idx < (int)g_prof[kind].size()) (void)hipEventRecord(g_prof[kind][idx].b, st);
+}
+
+// ---- run-time tuning knobs (spp_tune) ----
+static std::atomic<int> g_gather_wg_per_cu{0};   // 0: not read from the environment yet
+int gather_wg_per_cu() {
+  int v = g_gather_wg_per_cu.load(std::memory_order_relaxed);
+  if (v <= 0) {
+    const char* e = getenv("SPP_GATHER_WG_PER_CU");
+    v = e ? atoi(e) : 16;
+    if (v < 1) v = 1;
+    g_gather_wg_per_cu.store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 
 // ---- asynchronously detected data errors (spp_async_errors) ----
@@ -102,6 +117,17 @@ int spp_async_errors(int device, int clear) {
   }
   const int32_t v = clear ? __atomic_exchange_n(w, 0, __ATOMIC_ACQ_REL) : __atomic_load_n(w, __ATOMIC_ACQUIRE);
   return (int)(v & 0x7fffffff);
+}
+
+int spp_tune(const char* key, int value) {
+  if (!key) return SPP_ERR_INVALID;
+  if (!strcmp(key, "gather_wg_per_cu")) {
+    const int prev = spp::gather_wg_per_cu();
+    if (value > 0) spp::g_gather_wg_per_cu.store(value, std::memory_order_relaxed);
+    return prev;
+  }
+  spp::set_error("spp_tune: unknown knob '%s'", key);
+  return SPP_ERR_INVALID;
 }
 
 void spp_profile_enable(int on) {

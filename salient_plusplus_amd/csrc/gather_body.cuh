@@ -27,6 +27,9 @@ constexpr int kGatherThreads = 256;
 #endif
 constexpr int kGatherUnroll = SPP_GATHER_UNROLL;
 
+// workgroups per compute unit a row gather may put on the chip (spp_tune("gather_wg_per_cu"), SPP_GATHER_WG_PER_CU; api.hip)
+int gather_wg_per_cu();
+
 struct GatherGeom {
   int vec;        // bytes per lane access (16/8/4/2/1)
   int chunks;     // row_bytes / vec
@@ -47,11 +50,7 @@ static inline GatherGeom gather_geometry(const void* src, const void* dst, int64
   const int gpb = kGatherThreads >> g.lpr_log2;
   const int64_t rows_per_iter = (int64_t)gpb * kGatherUnroll;
   g.grid = (n + rows_per_iter - 1) / rows_per_iter;
-  static const int64_t max_grid = [] {  // 256 CUs x k workgroups: grid-stride beyond that
-    const char* e = getenv("SPP_GATHER_WG_PER_CU");
-    const int k = e ? atoi(e) : 16;
-    return (int64_t)256 * (k < 1 ? 1 : k);
-  }();
+  const int64_t max_grid = (int64_t)256 * gather_wg_per_cu();  // 256 CUs x k workgroups: grid-stride beyond that
   if (g.grid > max_grid) g.grid = max_grid;
   if (g.grid < 1) g.grid = 1;
   return g;

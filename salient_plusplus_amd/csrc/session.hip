@@ -94,6 +94,7 @@ struct spp_session {
   std::vector<hipEvent_t> export_done;   // per slot
   std::vector<char> export_recorded;     // per slot
   int64_t chain_launched = 0;            // groups whose sampling chain was launched (guarded by mu)
+  int refill_lag = 0;                    // a freed slot-set is refilled this many groups later (see launcher_main)
   // Launcher thread: enqueues the ~40 kernel launches of a group's chain off the consumer thread
   // (they cost 0.2-0.5 ms of host time per group, which used to stall the consumer at every group
   // boundary).  It is the counterpart of the reference's worker threads, with the GPU doing the work.
@@ -269,13 +270,22 @@ static void trace_dump() {
   g_trace.clear();
 }
 
+// how many chains may be in flight beyond the groups the consumer has finished: all slot-sets, minus the refill lag
+static inline int64_t launch_window(const spp_session* s) { return (int64_t)s->num_sets - s->refill_lag; }
+
+// Refill lag (round 4).  A chain enqueued the moment a slot-set is handed back waits, on the GPU, for that set's last
+// delivery -- so it can only START once the deliveries before it are done, and a consumer that synchronises soon after
+// (a short timed window, an epoch end, any host read) waits for the whole chain, alone on the GPU and latency bound
+// (0.6-0.7 ms for 16 batches).  With a lag of one group the launcher refills the set that was handed back one group
+// EARLIER: its deliveries completed long ago, the chain starts the moment it is enqueued -- which, for a consumer that
+// runs ahead of the GPU, is while the deliveries of the current group are still queued -- and runs beside them.
 static void launcher_main(spp_session* s) {
   (void)hipSetDevice(s->cfg.device);
   std::unique_lock<std::mutex> lk(s->mu);
   for (;;) {
     s->cv.wait(lk, [s] {
       return s->stop || (s->launch_rc == SPP_OK && s->chain_launched < s->num_groups &&
-                         s->chain_launched < s->groups_consumed + s->num_sets);
+                         s->chain_launched < s->groups_consumed + launch_window(s));
     });
     if (s->stop) return;
     const int64_t g = s->chain_launched;
@@ -631,6 +641,13 @@ extern "C" spp_status spp_session_create(const spp_session_cfg* cfg, spp_session
   }
   s->G = G;
   s->num_sets = sets;
+  {  // SPP_REFILL_LAG (groups; default 1): only with three or more slot-sets -- with two a lag would serialise.
+     // Measured on S-papers (profiles/r04_ab_refill_lag.txt): 20-step windows 0.1363-0.1391 -> 0.1299-0.1305 ms per
+     // step, 192-step windows 0.124-0.129 -> 0.122-0.124; a lag of 2, or a fifth slot-set for the lag, gives no more.
+    const char* e = getenv("SPP_REFILL_LAG");
+    const int lag = e ? atoi(e) : 1;
+    s->refill_lag = (sets >= 3 && lag > 0) ? std::min(lag, sets - 2) : 0;
+  }
   s->num_groups = (nb + G - 1) / G;
 
   s->streams.assign((size_t)sets, nullptr);
@@ -1057,7 +1074,7 @@ extern "C" spp_status spp_session_quiesce(spp_session* s) {
   {
     std::unique_lock<std::mutex> lk(s->mu);
     s->cv.wait(lk, [s] {
-      const int64_t target = std::min<int64_t>(s->num_groups, s->groups_consumed + s->num_sets);
+      const int64_t target = std::min<int64_t>(s->num_groups, s->groups_consumed + launch_window(s));
       const bool launcher_idle = s->launch_rc != SPP_OK || s->chain_launched >= target;
       const bool exchanger_idle = !s->tr || s->issue_on_consumer || s->exchange_rc != SPP_OK ||
                                   s->launch_rc != SPP_OK || s->exchange_launched >= target;

@@ -106,15 +106,29 @@ def leg_gather():
     step(fixed)
 
 
+def capped(fn, wg):
+    """the leg with the row gather / delivery grid capped at `wg` workgroups per compute unit"""
+    def run():
+        L.spp_tune(b"gather_wg_per_cu", wg)
+        fn()
+        L.spp_tune(b"gather_wg_per_cu", 16)
+    return run
+
+
 fns = {"resident": leg_resident, "rotate": leg_rotate, "data": leg_data, "decoupled": leg_decoupled, "gather": leg_gather}
+for w in (1, 2, 4, 8):
+    fns[f"gather_wg{w}"] = capped(leg_gather, w)
+    fns[f"data_wg{w}"] = capped(leg_data, w)
 res = {k: [] for k in legs}
 host = {k: [] for k in legs}
+insitu = {}
 for r in range(rounds):
     for k in legs:
         fn = fns[k]
         for _ in range(8):
             fn()
         torch.cuda.synchronize()
+        L.spp_profile_enable(4)          # every 4th delivery launch and every chain timed with HIP events on their streams
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
@@ -122,7 +136,14 @@ for r in range(rounds):
         torch.cuda.synchronize()
         res[k].append((time.perf_counter() - t0) / steps * 1e3)
         host[k].append((t1 - t0) / steps * 1e3)
+        for kind, name in ((0, "deliver/gather"), (2, "chain")):
+            ms, n, u = C.c_double(0), C.c_int64(0), C.c_int64(0)
+            L.spp_profile_read(kind, C.byref(ms), C.byref(n), C.byref(u))
+            if n.value:
+                insitu.setdefault((k, name), []).append(ms.value / n.value * 1e3)
+        L.spp_profile_enable(0)
 for k in legs:
     v = res[k]
     print(f"OVERLAP_AB {arch} {k:10s} mean {sum(v) / len(v):.4f} ms/step  windows " + " ".join(f"{x:.3f}" for x in v) +
-          f"  | host enqueue ms/step {sum(host[k]) / len(host[k]):.3f}", flush=True)
+          f"  | host enqueue ms/step {sum(host[k]) / len(host[k]):.3f}" +
+          "".join(f"  | {name} in situ {sum(v2) / len(v2):.0f} us per launch" for (kk, name), v2 in insitu.items() if kk == k), flush=True)
