@@ -1754,7 +1754,10 @@ template <int VEC>
 __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
   if (b < a.nb_x) {
     if (!a.asm_on) {
-      gather_rows_body<VEC, int32_t>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
+#ifndef SPP_DELIVER_NT
+#define SPP_DELIVER_NT false   // non-temporal LOADS of the source rows (measurement aid: profiles/r04_ab_INDEX.md)
+#endif
+      gather_rows_body<VEC, int32_t, SPP_DELIVER_NT>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
                                      a.nb_x, a.x_src_stride);
     } else {
       // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes

@@ -95,6 +95,7 @@ struct spp_session {
   std::vector<char> export_recorded;     // per slot
   int64_t chain_launched = 0;            // groups whose sampling chain was launched (guarded by mu)
   int refill_lag = 0;                    // a freed slot-set is refilled this many groups later (see launcher_main)
+  int64_t pending_consumed = -1;         // consumer thread only: groups fully consumed, not yet told to the launcher
   // Launcher thread: enqueues the ~40 kernel launches of a group's chain off the consumer thread
   // (they cost 0.2-0.5 ms of host time per group, which used to stall the consumer at every group
   // boundary).  It is the counterpart of the reference's worker threads, with the GPU doing the work.
@@ -311,6 +312,18 @@ static void notify_group_consumed(spp_session* s, int64_t groups_fully_consumed)
     s->groups_consumed = groups_fully_consumed;
   }
   s->cv.notify_all();
+}
+
+// The launcher is told about a finished group when the consumer COMES BACK for more (the next spp_session_next* call),
+// not at the export that finished it: a consumer that synchronises at a group boundary -- a timed window that ends there,
+// an evaluation loop, an epoch end -- then does not find a freshly enqueued refill chain (0.6 ms alone on the GPU) in front
+// of its synchronize; the chain is enqueued with its next request instead and runs beside the following deliveries.
+static void defer_group_consumed(spp_session* s, int64_t groups_fully_consumed) { s->pending_consumed = groups_fully_consumed; }
+static void flush_group_consumed(spp_session* s) {
+  if (s->pending_consumed >= 0) {
+    notify_group_consumed(s, s->pending_consumed);
+    s->pending_consumed = -1;
+  }
 }
 
 // consumer side: block until the chain of group g has been enqueued (its completion event exists)
@@ -776,7 +789,7 @@ static spp_status retire_current(spp_session* s) {
   s->current_slot = -1;
   const int64_t g = b / s->G;
   const bool last_of_group = (b + 1 == (int64_t)s->ranges.size()) || ((b + 1) % s->G == 0);
-  if (last_of_group) notify_group_consumed(s, g + 1);
+  if (last_of_group) defer_group_consumed(s, g + 1);
   return SPP_OK;
 }
 
@@ -831,6 +844,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
     spp_status rc = retire_current(s);
     if (rc != SPP_OK) return rc;
   }
+  flush_group_consumed(s);
   if (s->next_to_deliver == (int64_t)s->ranges.size()) return 0;  // blocking_get_batch -> None
   const int64_t b = s->next_to_deliver;
   const int64_t g = b / s->G;
@@ -866,6 +880,7 @@ extern "C" int spp_session_try_next(spp_session* s, spp_batch_desc* out) {
     set_error("spp_session_try_next: NULL argument");
     return SPP_ERR_INVALID;
   }
+  if (s->current_slot < 0) flush_group_consumed(s);
   if (s->current_slot < 0 && s->next_to_deliver < (int64_t)s->ranges.size()) {
     // is the next batch ready?  (chain launched and complete; with the native exchange: issued)
     const int64_t g = s->next_to_deliver / s->G;
@@ -943,7 +958,7 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
       const int64_t g = s->current_group;
       s->current_group = -1;
       s->group_member = 0;
-      notify_group_consumed(s, g + 1);
+      defer_group_consumed(s, g + 1);
     }
     return SPP_OK;
   }
@@ -962,6 +977,7 @@ extern "C" int spp_session_next_group(spp_session* s, int32_t block, spp_batch_d
     return SPP_ERR_STATE;
   }
   const int64_t nb = (int64_t)s->ranges.size();
+  flush_group_consumed(s);
   if (s->next_to_deliver == nb) return 0;
   if (s->next_to_deliver % s->G != 0) {
     set_error("spp_session_next_group: batch %lld is in the middle of a group (mix per-batch and group calls only "
@@ -1058,7 +1074,7 @@ extern "C" spp_status spp_session_export_group(spp_session* s, int32_t n, const 
   SPP_HIP_TRY(hipEventRecord(s->export_done[(size_t)slot0], st));
   s->export_recorded[(size_t)slot0] = 1;
   s->current_group = -1;
-  notify_group_consumed(s, g + 1);
+  defer_group_consumed(s, g + 1);
   return SPP_OK;
 }
 
@@ -1071,6 +1087,7 @@ extern "C" spp_status spp_session_exchange_stats(const spp_session* s, int64_t* 
 
 extern "C" spp_status spp_session_quiesce(spp_session* s) {
   SPP_REQUIRE(s, "spp_session_quiesce: NULL session");
+  // (a deferred "group consumed" stays deferred: quiesce drains what HAS been enqueued, it does not start a refill)
   {
     std::unique_lock<std::mutex> lk(s->mu);
     s->cv.wait(lk, [s] {
