@@ -148,9 +148,21 @@ def launch_ranks(a) -> int:
     import socket
     import subprocess
     n_dev = visible_gpu_count()
+    counted_by = "kfd topology (sysfs)"
+    if n_dev < a.gpus and "SPP_KFD_TOPOLOGY" not in os.environ:
+        # sysfs shows fewer GPUs than asked for (a sandbox may hide the topology): ask a CHILD process that is free to
+        # bring up the HIP runtime and exits -- this process still never loads it
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                               text=True, timeout=180)
+            n_child = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+        except Exception:  # noqa: BLE001
+            n_child = 0
+        if n_child > n_dev:
+            n_dev, counted_by = n_child, "child process (torch.cuda.device_count)"
     if a.launch_dry_run:
         maps = open("/proc/self/maps").read()
-        print(json.dumps({"launcher": True, "visible_gpus": n_dev, "ranks_wanted": a.gpus, "torch_imported": "torch" in sys.modules,
+        print(json.dumps({"launcher": True, "visible_gpus": n_dev, "counted_by": counted_by, "ranks_wanted": a.gpus, "torch_imported": "torch" in sys.modules,
                           "libamdhip64_mapped": "libamdhip64" in maps, "libhsa_runtime_mapped": "libhsa-runtime64" in maps}), flush=True)
     if n_dev < a.gpus:
         print(f"[bench] --gpus {a.gpus} needs {a.gpus} GPUs, this node shows {n_dev}: refusing to run fewer ranks "
