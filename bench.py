@@ -663,6 +663,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["SPP_BENCH_STALL_DUMP"]), repeat=True)
     win = []                                      # (seconds, edges, nodes) per window
+    prof_cum = []                                 # cumulative (ms, launches) of the timed delivery launches after each window
     chain_alg_bytes = 0                           # the sampler's algorithmic bytes over the timed region (this rank)
     for _w in range(R):
         edges = nodes = 0
@@ -694,6 +695,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         win.append((time.perf_counter() - t0, float(edges), float(nodes)))
+        # (outside the window's clock) the delivery launches timed so far: per-window in-situ duration of the dominant kernel,
+        # which tells a slow window of the GPU (longer launches) from one of the host or the queue (same launches, more gaps)
+        _ms, _n, _u = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        nat.check(L.spp_profile_read(1 if (distributed and not native) else 0, C.byref(_ms), C.byref(_n), C.byref(_u)))
+        prof_cum.append((_ms.value, _n.value))
     xb1 = feeder.exchange_bytes()
     dev_allocs_timed = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)) - dev_allocs0
     if os.environ.get("SPP_BENCH_STALL_DUMP"):
@@ -851,7 +857,10 @@ def main():
                         "ms_per_step_mean": dt_mean / a.steps * 1e3,
                         "ms_per_step_trimmed_mean": dt_trimmed / a.steps * 1e3,   # without the slowest and the fastest of >= 8 windows
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
-                        "ms_per_step_all": [round(v, 5) for v in window_ms]},
+                        "ms_per_step_all": [round(v, 5) for v in window_ms],
+                        # in-situ duration of the timed delivery launches of each window (rank 0; live HIP events)
+                        "deliver_us_all": [round(1e3 * (b[0] - a_[0]) / max(1, b[1] - a_[1]), 1)
+                                           for a_, b in zip([(0.0, 0)] + prof_cum[:-1], prof_cum)]},
             "timed_region_s": timed_total_s,          # all R windows (also under "windows")
             "hbm": {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
                     "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),

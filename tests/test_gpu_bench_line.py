@@ -44,6 +44,7 @@ def _check_common(d, n_gpus):
     assert len(allw) == w["n"]
     assert abs(d["ms_per_step"] - sum(allw) / len(allw)) <= 1e-4 * d["ms_per_step"] + 1e-5
     assert "ms_per_step_trimmed_mean" in w and "ms_per_step_median" in w
+    assert len(w["deliver_us_all"]) == w["n"] and all(v >= 0 for v in w["deliver_us_all"])   # per-window in-situ delivery time
     assert abs(d["value"] - d["sampled_edges_per_batch"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
