@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPP_ABI_VERSION 4
+#define SPP_ABI_VERSION 5
 #define SPP_MAX_HOPS 8
 #define SPP_MAX_PARTS 64
 

@@ -166,7 +166,7 @@ def load():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.spp_abi_version() != 4:
+        if L.spp_abi_version() != 5:
             raise SppError("libspp_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/spp.h but not exported"
         assert name in nat.SIGNATURES, f"{name} has no ctypes signature"
     assert set(nat.SIGNATURES) == set(syms)
-    assert L.spp_abi_version() == 4
+    assert L.spp_abi_version() == 5
     assert L.spp_batch_seed(64) == 64 * 17 + 5
 
 
