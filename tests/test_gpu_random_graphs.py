@@ -74,3 +74,12 @@ def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hub
             np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
             np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
             assert tuple(size) == tuple(hop.size)
+
+
+@pytest.mark.parametrize("k", range(len(FANOUTS)))
+def test_larger_random_graph_with_hubs_against_the_oracle(fs, k):
+    """one larger case per fan-out list (20 k vertices, three hubs collecting 40 % of all edges, 5 batches of 512 seeds with
+    duplicates, 16 slots): the sizes hypothesis rarely draws"""
+    test_random_graph_against_the_oracle.hypothesis.inner_test(
+        fs, seed=1000 + k, n=20_000, mean_deg=12.0 + k, zero_frac=0.05, n_hubs=3, hub_share=0.4, sizes=FANOUTS[k], bs=512,
+        n_batches=5, slots=16, dup=bool(k & 1))
