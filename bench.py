@@ -317,6 +317,18 @@ def count_edges(batch) -> int:
     return sum(int(adj.adj_t.nnz()) for adj in batch.adjs)
 
 
+def edges_and_sampler_bytes(batch):
+    """(sampled edges, sampler_algorithmic_bytes) in one pass over the hops: this runs inside the timed loop, and the short
+    workloads are host bound"""
+    edges = alg = 0
+    for adj in batch.adjs:
+        e = int(adj.adj_t.nnz())
+        n_src, n_dst = adj.size
+        edges += e
+        alg += 24 * int(n_dst) + 16 * e + 8 * (int(n_src) - int(n_dst))
+    return edges, alg
+
+
 def sampler_algorithmic_bytes(batch) -> int:
     """SURVEY 8(d), per hop: T (two rowptr reads + the out_rowptr write per target) x 24 + E (col read + out_col write
     per sampled edge) x 16 + dU (the n_id write per new node) x 8, restating sample_cpu.hpp:25-143."""
@@ -672,9 +684,10 @@ def main():
         for _ in range(a.steps):
             ts = time.perf_counter()
             b = feeder.next()
-            edges += count_edges(b)
+            e_, a_ = edges_and_sampler_bytes(b)
+            edges += e_
             nodes += b.x.size(0)
-            chain_alg_bytes += sampler_algorithmic_bytes(b)
+            chain_alg_bytes += a_
             if step_t is not None:
                 step_t.append((time.perf_counter() - ts) * 1e6)
                 if step_t[-1] > 50000:            # a stall: what the caching allocator did meanwhile
