@@ -593,6 +593,9 @@ class Session:
         # SPP_GROUP_FETCH=0: spp_session_next / spp_session_export per batch, nine allocations each.
         self._member_mode = not self._group_mode and os.environ.get("SPP_GROUP_FETCH", "1") != "0"
         self._open = None                          # [next member, fetched group] while a group is partly handed out
+        self.export_stream = None                  # set by a consumer that delivers on ONE fixed stream (DevicePrefetcher): the
+        self._export_raw = None                    # per-batch path then skips the current-stream lookup / stream context
+        self.last_arenas = None                    # the (<= 3) storages behind the views of the batch handed out last
         self._gdescs = (nat.BatchDesc * max(16, int(self._L.spp_session_group_size(self._h))))()   # one per batch of a group
         self._ready = collections.deque()          # (record, ready event, delivery stream) of delivered batches
         self._ended = False
@@ -674,6 +677,13 @@ class Session:
             self.close()
         except Exception:
             pass
+
+    def set_export_stream(self, stream):
+        """A consumer that delivers every batch on ONE stream says so once: the per-batch path then uses that stream's
+        handle directly (no current-stream lookup, no stream context around every request) and allocates a group's
+        arenas under it.  None: back to "the caller's current stream at each request"."""
+        self.export_stream = stream
+        self._export_raw = stream.cuda_stream if stream is not None else None
 
     @property
     def consumer_stream(self):
@@ -789,7 +799,7 @@ class Session:
         grp = self._open_group(block)
         if grp is None:
             return False
-        n, outs, records, xa, ya, flags = grp
+        n, outs, records, xa, ya, flags, _arenas = grp
         dev = self._dev
         distributed, native, count_remote, rank = flags
         stream = torch.cuda.current_stream(dev)
@@ -816,14 +826,19 @@ class Session:
         for -- the host work of a batch is one export call and the record, the GPU sees the same per-batch launches as
         with batch-at-a-time calls."""
         if self._open is None:
-            grp = self._open_group(block)
+            if self.export_stream is not None:     # the group's arenas belong to the stream its batches are delivered on
+                with torch.cuda.stream(self.export_stream):
+                    grp = self._open_group(block)
+            else:
+                grp = self._open_group(block)
             if grp is None:
                 return None
             self._open = [0, grp]
-        i, (n, outs, records, xa, ya, flags) = self._open
+        i, (n, outs, records, xa, ya, flags, arenas) = self._open
+        self.last_arenas = arenas
         o = outs[i]
         # (the raw handle of the caller's current stream: torch.cuda.current_stream() builds a Stream object, 2-3 us)
-        raw = torch._C._cuda_getCurrentRawStream(self._dev.index)
+        raw = self._export_raw if self._export_raw is not None else torch._C._cuda_getCurrentRawStream(self._dev.index)
         nat.check(self._L.spp_session_export(self._h, C.byref(o.mfg), xa[0], xa[1], xa[2], xa[3], o.x_out,
                                              ya[0], ya[1], ya[2], o.y_out, C.c_void_p(raw)))
         rec = self._make_record(records[i], flags)
@@ -956,7 +971,8 @@ class Session:
             records.append((x, y, adjs, (start, stop), n_id, nids, flat, cached, perm, pc, U))
         xa = self._x_args if (want_x and not native) else (None, 0, 0, 0)
         ya = self._y_args if want_y else (None, 0, 0)
-        return n, outs, records, xa, ya, (distributed, native, count_remote, rank)
+        arenas = [t for t in (arena, x_arena if want_x else None, y_arena if want_y else None) if t is not None]
+        return n, outs, records, xa, ya, (distributed, native, count_remote, rank), arenas
 
     def _proto_record(self, x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank):
         b = ProtoDistributedBatch()

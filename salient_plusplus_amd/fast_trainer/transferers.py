@@ -406,6 +406,13 @@ class DevicePrefetcher(DeviceIterator):
         # the GPU sampler offers a persistent delivery stream of its own (distinct hardware queue
         # from the sampling streams); otherwise a plain side stream as in the reference
         self.streams = [sess_stream] if sess_stream is not None else [torch.cuda.Stream(device) for device in devices]
+        # GPU Session in its default (group fetch, per-batch launch) mode: it is told the delivery stream once and a request
+        # needs no stream context; the batch's tensors are views of <= 3 arenas, which is all record_stream has to see
+        sess = getattr(it, "session", None)
+        self._direct = bool(sess_stream is not None and getattr(sess, "_member_mode", False) and
+                            hasattr(sess, "set_export_stream"))
+        if self._direct:
+            sess.set_export_stream(sess_stream)
         self.next = []
         self.next_events = []
         self.sampling_times = []
@@ -414,6 +421,14 @@ class DevicePrefetcher(DeviceIterator):
     def preload(self, timing=True):
         self.next = []
         self.next_events = []
+        if self._direct:
+            t0 = time.perf_counter_ns()
+            batch = next(self.it, None)
+            if batch is not None:
+                self.next.append(batch)
+                self.next_events.append(None)
+            self.sampling_times.append(time.perf_counter_ns() - t0)
+            return
         for device, stream in zip(self.devices, self.streams):
             t0 = time.perf_counter_ns()
             with torch.cuda.stream(stream):
@@ -444,8 +459,13 @@ class DevicePrefetcher(DeviceIterator):
         if not ret:
             torch.cuda.synchronize()
             raise StopIteration
-        for cur_stream, batch in zip(cur_streams, ret):
-            batch.record_stream(cur_stream)
+        arenas = getattr(self.it.session, "last_arenas", None) if self._direct else None
+        if arenas:            # (of the batch handed out now: preload() below moves the Session on to the next one)
+            for a in arenas:
+                a.record_stream(cur_streams[0])
+        else:
+            for cur_stream, batch in zip(cur_streams, ret):
+                batch.record_stream(cur_stream)
         self.preload()
         return ret
 
