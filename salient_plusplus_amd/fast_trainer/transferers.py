@@ -105,6 +105,17 @@ class _HipFeatureOps:
         return out
 
 
+class _NoContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_CTX = _NoContext()
+
+
 class _SideStream:
     """`with` context running on a side stream of a CUDA device, or inline on a CPU 'device'
     (the CPU form only exists so the exchange logic can be exercised with gloo in tests)."""
@@ -185,6 +196,14 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.NUMBER_OF_SENT_BYTES = 0
         self.ITERATION = 0
         self._exhausted = False
+        # native exchange, default (group fetch, per-batch launch) mode: as in DevicePrefetcher the Session is told its
+        # delivery stream once -- no stream context around every request, record_stream on the batch's arenas
+        sess = self.it.session
+        self._direct = bool(self.native and self.side.cuda and getattr(sess, "_member_mode", False) and
+                            hasattr(sess, "set_export_stream"))
+        if self._direct:
+            sess.set_export_stream(self.side.stream)
+        self._next_arenas = None
         if self.native:
             self._advance(produce_output=True)
         else:
@@ -315,11 +334,12 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         if self.native:
             if not produce_output:
                 return
-            with self.side:
+            with (_NO_CTX if self._direct else self.side):
                 runtime_stats_cuda.start_region("sampling2")
                 proto = next(self.it, None)
                 runtime_stats_cuda.end_region("sampling2")
                 self.next_event = _ready_event(self.it) if proto is not None else None
+                self._next_arenas = getattr(self.it.session, "last_arenas", None) if (self._direct and proto is not None) else None
                 if proto is None:
                     self.next = None
                     sent, _recv = self.it.session.exchange_bytes()
@@ -369,8 +389,13 @@ class DeviceDistributedPrefetcher(DeviceIterator):
                 torch.cuda.synchronize()
             raise StopIteration
         if self.side.cuda:
-            for b in ret:
-                b.record_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            if self._next_arenas:        # (of the batch handed out now; _advance below replaces them)
+                for a in self._next_arenas:
+                    a.record_stream(cur)
+            else:
+                for b in ret:
+                    b.record_stream(cur)
         if self.native:
             self._advance(produce_output=True)
         else:
