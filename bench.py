@@ -74,6 +74,9 @@ def parse():
                     help="timed windows of --steps steps run back to back, pipeline kept full in between; the "
                          "reported ms_per_step / value are the plain mean over the windows "
                          "(0 = max(6, 2 * ceil(128 / steps)))")
+    ap.add_argument("--fanouts", default="",
+                    help="comma-separated fan-outs instead of the workload's own (e.g. 20,20,20: the reference's batchwise "
+                         "inference; a hop < 0 or > 32 takes the generic sampling path: one batch per launch, a host sync per hop)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="launcher only: print the GPU count found without the HIP runtime and whether libamdhip64 is mapped "
                          "into the launcher process, start nothing")
@@ -505,6 +508,8 @@ def main():
     t_build = time.perf_counter() - t_build
     N, F = wl.num_nodes, wl.x.size(1)
     sizes, bs = wl.fanouts, wl.batch_size
+    if a.fanouts:
+        sizes = [int(v) for v in a.fanouts.split(",")]
     y2 = wl.y.unsqueeze(-1)
 
     if not distributed:

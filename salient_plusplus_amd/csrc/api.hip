@@ -15,30 +15,34 @@ static thread_local char g_err[1024] = "";
 struct ProfRec {
   hipEvent_t a, b;
   int64_t units;
+  bool ended;   // b has been recorded (a chain is timed from the launcher thread: a reader may come in between)
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static int g_prof_every = 1;                 // time every n-th launch of a kind (spp_profile_enable(n))
 static int64_t g_prof_seen[SPP_PROF_KINDS] = {};
 static std::vector<ProfRec> g_prof[SPP_PROF_KINDS];
+static int g_prof_gen = 0;   // bumped by spp_profile_enable: a prof_end that belongs to an earlier recording is dropped
 
 int prof_begin(int kind, hipStream_t st, int64_t units) {
   if (!g_prof_on) return -1;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if ((g_prof_seen[kind]++ % (kind == SPP_PROF_CHAIN ? 1 : g_prof_every)) != 0) return -1;
-  if (g_prof[kind].size() >= (1u << 16)) return -1;
+  if (g_prof[kind].size() >= (1u << 16) - 1) return -1;
   ProfRec r{};
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
   r.units = units;
   (void)hipEventRecord(r.a, st);
   g_prof[kind].push_back(r);
-  return (int)g_prof[kind].size() - 1;
+  return ((g_prof_gen & 0x7fff) << 16) | ((int)g_prof[kind].size() - 1);
 }
 
-void prof_end(int kind, int idx, hipStream_t st) {
-  if (idx < 0) return;
+void prof_end(int kind, int token, hipStream_t st) {
+  if (token < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (idx < (int)g_prof[kind].size()) (void)hipEventRecord(g_prof[kind][idx].b, st);
+  if ((token >> 16) != (g_prof_gen & 0x7fff)) return;  // the recording it was started in has been cleared since
+  const int idx = token & 0xffff;
+  if (idx < (int)g_prof[kind].size() && hipEventRecord(g_prof[kind][idx].b, st) == hipSuccess) g_prof[kind][idx].ended = true;
 }
 
 // ---- run-time tuning knobs (spp_tune) ----
@@ -139,6 +143,7 @@ void spp_profile_enable(int on) {
     }
     v.clear();
   }
+  ++spp::g_prof_gen;
   spp::g_prof_on = on != 0;
   spp::g_prof_every = on > 1 ? on : 1;
   for (auto& c : spp::g_prof_seen) c = 0;
@@ -150,9 +155,12 @@ spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64
   double ms = 0;
   int64_t n = 0, u = 0;
   for (auto& r : spp::g_prof[kind]) {
-    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    if (!r.ended) continue;  // still being enqueued by another thread: not part of this reading
     float t = 0;
-    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+      (void)hipGetLastError();  // do not leave the failure behind for the caller's next HIP check
+      continue;
+    }
     ms += t;
     u += r.units;
     ++n;

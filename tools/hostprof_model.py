@@ -63,6 +63,41 @@ for name, get in (("resident", lambda: fixed), ("data", lambda: next(it)[0])):
     leg(get, 20)
     g, s = leg(get, steps)
     print(f"HOSTPROF {name}: next() {g:.1f} us, step() {s:.1f} us of host time per step (queue empty before each step)", flush=True)
+def pieces(get, n):
+    acc = [0.0] * 6
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t = [time.perf_counter()]
+        b = get()
+        t.append(time.perf_counter())
+        opt.zero_grad(set_to_none=True)
+        t.append(time.perf_counter())
+        out = model(b.x, b.adjs)
+        t.append(time.perf_counter())
+        loss = torch.nn.functional.nll_loss(out, b.y.reshape(-1))
+        t.append(time.perf_counter())
+        loss.backward()
+        t.append(time.perf_counter())
+        opt.step()
+        t.append(time.perf_counter())
+        for k in range(6):
+            acc[k] += t[k + 1] - t[k]
+    return [v / n * 1e6 for v in acc]
+
+
+for name, get in (("resident", lambda: fixed), ("data", lambda: next(it)[0])):
+    pieces(get, 20)
+    v = pieces(get, steps)
+    print(f"HOSTPIECES {name}: next {v[0]:.1f}  zero_grad {v[1]:.1f}  forward {v[2]:.1f}  loss {v[3]:.1f}  backward {v[4]:.1f}  "
+          f"optimizer {v[5]:.1f} us", flush=True)
+del fixed
+import gc
+gc.collect()
+for name, get in (("data, previous batch dropped before the step", lambda: next(it)[0]),):
+    v = pieces(get, steps)
+    print(f"HOSTPIECES {name}: next {v[0]:.1f}  zero_grad {v[1]:.1f}  forward {v[2]:.1f}  loss {v[3]:.1f}  backward {v[4]:.1f}  "
+          f"optimizer {v[5]:.1f} us", flush=True)
+sys.exit(0)
 for name, get in (("resident", lambda: fixed), ("data", lambda: next(it)[0])):
     pr = cProfile.Profile()
     leg(get, steps, pr)
