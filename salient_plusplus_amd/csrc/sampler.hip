@@ -2790,7 +2790,7 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
   if (blocks == 0) return SPP_OK;
   // Occupancy cap.  One launch covers the group, so without a cap its workgroups would hold every wave slot of the
   // chip for the whole ~0.8 ms and the sampling chains of the next groups -- whose tile kernels need 16 free wave
-  // slots on ONE compute unit -- would starve behind it (k_bucket_hist of hop 1: 0.8 ms per launch).  The row
+  // slots on ONE compute unit -- would starve behind it (the tile kernel of hop 1: 0.8 ms per launch).  The row
   // gather is a grid-stride loop: SPP_DELIVER_WG_PER_CU workgroups (4 wavefronts each) per compute unit.
   static const int wg_per_cu = [] {
     const char* e = getenv("SPP_DELIVER_WG_PER_CU");
