@@ -1,5 +1,6 @@
 """Host time of one optimisation step of models.SAGE, resident batch vs fed by the data path, with the GPU queue empty
-before every step (no back-pressure in the figures), and a cProfile of each leg.  usage: hostprof_model.py [steps=200]"""
+before every step (no back-pressure in the figures): whole step, then piece by piece (next / zero_grad / forward / loss /
+backward / optimizer); PROFILE=1 adds a cProfile of each leg.  usage: hostprof_model.py [steps=200]"""
 import cProfile
 import os
 import pstats
@@ -97,7 +98,9 @@ for name, get in (("data, previous batch dropped before the step", lambda: next(
     v = pieces(get, steps)
     print(f"HOSTPIECES {name}: next {v[0]:.1f}  zero_grad {v[1]:.1f}  forward {v[2]:.1f}  loss {v[3]:.1f}  backward {v[4]:.1f}  "
           f"optimizer {v[5]:.1f} us", flush=True)
-sys.exit(0)
+if os.environ.get("PROFILE") != "1":
+    sys.exit(0)
+fixed = next(it)[0]
 for name, get in (("resident", lambda: fixed), ("data", lambda: next(it)[0])):
     pr = cProfile.Profile()
     leg(get, steps, pr)
