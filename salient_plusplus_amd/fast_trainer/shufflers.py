@@ -43,14 +43,22 @@ class Shuffler:
         if order is None:
             order = self._compute(e, self.generator)
         box = []
+        on_gpu = self.initial_idx.is_cuda
+
+        def ahead():
+            nxt = self._compute(e + 1, torch.Generator(device="cpu"))
+            # ids in HBM: the upload of the next permutation (9.6 MB for 1.2 M ids: 1 ms from pageable memory, with the GPU
+            # idle between two epochs) becomes an asynchronous copy out of pinned memory
+            box.append(nxt.pin_memory() if on_gpu else nxt)
         # (not a daemon thread: it runs for a few ms and is joined at interpreter exit)
-        th = threading.Thread(target=lambda: box.append(self._compute(e + 1, torch.Generator(device="cpu"))))
+        th = threading.Thread(target=ahead)
         th.start()
         self._ahead = (e + 1, th, box)
         return order
 
     def get_idx(self):
-        order = self._permutation().to(self.initial_idx.device)
+        order = self._permutation()
+        order = order.to(self.initial_idx.device, non_blocking=order.is_pinned())
         return self.initial_idx[order]
 
     def __getstate__(self):
