@@ -227,17 +227,12 @@ def _wgrad(g, a):
 
 
 def _tall_linear(a, w):
-    """a @ w.T for a very tall a [T, K]: in four row chunks the library picks a tile that runs 13 % faster than for the
-    single product at T = 164 k, N = K = 256 (206 against 236 us; tools/gemm_variants.py)"""
-    T = a.size(0)
-    if T < (1 << 16):
-        return a @ w.t()
-    out = torch.empty((T, w.size(0)), dtype=a.dtype, device=a.device)
-    wt = w.t().contiguous()
-    c = -(-T // 4)
-    for i in range(0, T, c):
-        torch.mm(a[i:i + c], wt, out=out[i:i + c])
-    return out
+    """a @ w.T for a very tall a [T, K].  Round 3 issued it in four row chunks (206 against 214-236 us for the single
+    product at T = 164 k, N = K = 256 then); with this stack's library F.linear(a, w) takes the transposed weight as it is and
+    runs as fast (201-204 against 207 us, tools/corun_gemm.py), and one launch instead of an empty + a transposed copy +
+    four products is 0.1 ms less host time per step: resident step 1.010-1.015 -> 0.995-0.997 ms, with the data path
+    1.140-1.156 -> 1.111-1.121 (tools/overlap_ab.py, SPP_SAGE_ONE_PRODUCT A/B of round 4)."""
+    return torch.nn.functional.linear(a, w)
 
 
 class _SageStack(torch.autograd.Function):
