@@ -220,10 +220,22 @@ def _wgrad(g, a):
     if slabs < 2:
         return g.t() @ a
     c = T // slabs
-    out = torch.bmm(a[:slabs * c].view(slabs, c, -1).transpose(1, 2), g[:slabs * c].view(slabs, c, -1)).sum(0).t()
-    if slabs * c < T:
-        out = out + g[slabs * c:].t() @ a[slabs * c:]
-    return out
+    acc = torch.bmm(a[:slabs * c].view(slabs, c, -1).transpose(1, 2), g[:slabs * c].view(slabs, c, -1)).sum(0)   # [K, N]
+    if slabs * c < T:      # the < `slabs` rows left over: accumulated in place (one launch; it was a product + an add)
+        acc.addmm_(a[slabs * c:].t(), g[slabs * c:])
+    return acc.t()
+
+
+def _split_wgrad(gW):
+    """[N, 2K] weight gradient of the [W_l | W_r] operand -> (grad W_l, grad W_r), each [N, K] contiguous, with ONE copy
+    launch for both: gW is the transposed view of a contiguous [2K, N] sum (see _wgrad), so its two halves are the two
+    [K, N] blocks of that buffer, transposed together."""
+    N, K2 = gW.shape
+    base = gW.t()
+    if not base.is_contiguous():
+        return gW[:, :K2 // 2].contiguous(), gW[:, K2 // 2:].contiguous()
+    both = base.view(2, K2 // 2, N).transpose(1, 2).contiguous()      # [2, N, K]
+    return both[0], both[1]
 
 
 def _tall_linear(a, w):
@@ -308,7 +320,7 @@ class _SageStack(torch.autograd.Function):
             A, W = operands[i], wcats[i]
             K = A.size(1) // 2
             gW = _wgrad(gZ, A)
-            grads[2 * i], grads[2 * i + 1] = gW[:, :K].contiguous(), gW[:, K:].contiguous()
+            grads[2 * i], grads[2 * i + 1] = _split_wgrad(gW)
             if i == 0:
                 break
             rowptr, col, T = hops[i]
