@@ -867,6 +867,18 @@ def main():
                     roof_s["traffic"] = mb * 1e6
                     roof_s["traffic_source"] = (f"profiles/{os.path.basename(pmc_txt[-1])}: fetch + write MB per batch of the chain's kernels from "
                                                 f"earlier rocprofv3 --pmc passes over this command (NOT measured in this run)")
+        if roof_s is not None and not distributed:
+            # context for the in-situ span: the chain ALONE on the GPU (two sampling streams, no deliveries), from the
+            # committed sampling-only run of this workload's default configuration -- not measured in this run
+            lone = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_chain_only_trace_report.txt")))
+            if lone and a.workload == "S-papers" and not a.fanouts:
+                import re
+                m_ = re.search(r"chain only: .*?([0-9.]+) us/batch", open(lone[-1]).read())
+                if m_:
+                    us = float(m_.group(1))
+                    roof_s["lone_chain"] = {"us_per_batch": us, "achieved_GBps_algorithmic": roof_s["algorithmic_bytes_per_batch"] / us / 1e3,
+                                            "achieved_GBps_traffic": (roof_s["traffic"] / us / 1e3) if roof_s["traffic"] else None,
+                                            "source": f"profiles/{os.path.basename(lone[-1])} (tools/microbench.py chain; NOT measured in this run)"}
         out = {
             "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
