@@ -18,7 +18,8 @@ def _p(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of the current stream of the current device (torch.cuda.current_stream() builds a Stream object: 5 us)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 class _MeanAggregate(torch.autograd.Function):
