@@ -1,7 +1,8 @@
 """Batch records, sampler configuration and sampler iterables of the training façade.
 
 This module offers the names the rest of SALIENT++ imports from ``fast_trainer.samplers`` -- the batch
-records (``PreparedBatch``, ``ProtoBatch``, ``ProtoDistributedBatch``), ``Adj__from_fast_sampler``,
+records (``PreparedBatch``, ``ProtoBatch``, ``ProtoDistributedBatch``, ``NumpyProtoDistributedBatch``),
+``Adj__from_fast_sampler``,
 ``FastSamplerConfig``, ``FastSampler`` / ``FastSamplerIter`` / ``FastPreSampler`` and the two statistics
 records -- with the field sets and call signatures of the reference (fast_trainer/samplers.py:22-30,
 :32-165, :213-268, :271-305, :331-423), on top of the MI355X ``fast_sampler`` module.
@@ -168,6 +169,36 @@ class ProtoDistributedBatch(NamedTuple):
 
     def get_num_communicated_nodes(self, local_rank):
         return sum(ids.numel() for owner, ids in enumerate(self.partition_nids) if owner != local_rank)
+
+
+class NumpyProtoDistributedBatch(NamedTuple):
+    """A ProtoDistributedBatch as host arrays, for saving batch statistics to .npz and plotting them (reference
+    fast_trainer/samplers.py:167-196: the same five fields; there ``from_proto_batch`` is switched off with an
+    ``assert False`` and its only caller, DeviceDistributedPrefetcher.collect_data, never reaches it).  Here the
+    conversion works: every tensor of the batch is copied out of HBM, so it is for diagnostics, not for the
+    training loop.  Each hop becomes a ``scipy.sparse.csr_matrix`` of T target rows over S source columns with
+    unit edge data."""
+    partition_nids: list
+    cache_specific_nids: object
+    perm_partition_to_mfg: object
+    adjs: list
+    seed_indices: object
+
+    @classmethod
+    def from_proto_batch(cls, batch: "ProtoDistributedBatch", ids: torch.Tensor):
+        import numpy as np
+        import scipy.sparse
+
+        def host(t):
+            return t.detach().cpu().numpy()
+
+        hops = []
+        for hop in batch.adjs:
+            rowptr, col, _ = hop.adj_t.csr()
+            t, s = hop.adj_t.sparse_sizes()
+            hops.append(scipy.sparse.csr_matrix((np.ones(col.numel(), dtype=np.float32), host(col), host(rowptr)), shape=(t, s)))
+        return cls(partition_nids=[host(n) for n in batch.partition_nids], cache_specific_nids=host(batch.cached_nids),
+                   perm_partition_to_mfg=host(batch.perm_partition_to_mfg), adjs=hops, seed_indices=host(ids[batch.idx_range]))
 
 
 # --------------------------------------------------------------------------------------------

@@ -27,8 +27,17 @@ from typing import Iterator, List, Optional
 import torch
 import torch.distributed as dist
 
-from .samplers import PreparedBatch, ProtoBatch, ProtoDistributedBatch
+from .samplers import NumpyProtoDistributedBatch, PreparedBatch, ProtoBatch, ProtoDistributedBatch
 from .utils import runtime_stats_cuda
+
+# nanoseconds per timer name, summed over the calls of aggregate_time (reference transferers.py:13-18: the hook its
+# Timer objects report to; reset by DeviceDistributedPrefetcher.print_stats)
+aggregate_time_results = dict()
+
+
+def aggregate_time(result):
+    """Timer callback: adds ``result.nanos`` to the running total kept under ``result.name``."""
+    aggregate_time_results[result.name] = aggregate_time_results.get(result.name, 0) + result.nanos
 
 
 class DeviceIterator(Iterator[List[PreparedBatch]]):
@@ -194,6 +203,7 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         self.next: Optional[list] = []
         self.next_event = None
         self.NUMBER_OF_SENT_BYTES = 0
+        self.ALL_BATCHES = []                   # batches the caller wants recorded by collect_data
         self.ITERATION = 0
         self._exhausted = False
         # native exchange, default (group fetch, per-batch launch) mode: as in DevicePrefetcher the Session is told its
@@ -406,7 +416,24 @@ class DeviceDistributedPrefetcher(DeviceIterator):
         return ret
 
     def print_stats(self):
-        return
+        aggregate_time_results.clear()          # reference :566-570: the totals are per epoch
+
+    def collect_data(self, data_collector=None, ids=None, save_all_batch_data_to_disk=False):
+        """End-of-epoch statistics hook of the reference's driver (transferers.py:843-887).  There the body is
+        switched off (``save_all_batch_data_to_disk = False``) and the call returns None; the same here by default.
+        With ``save_all_batch_data_to_disk=True`` the batches kept in ``ALL_BATCHES`` (the caller appends the ones it
+        wants recorded) are converted with NumpyProtoDistributedBatch and written through the collector's
+        ``get_epoch_data_filepath`` / ``np_savez_list``, one file per field; ``ids`` are the epoch's seed ids."""
+        if save_all_batch_data_to_disk and data_collector is not None and self.ALL_BATCHES:
+            columns = {k: [] for k in NumpyProtoDistributedBatch._fields}
+            seeds = ids if ids is not None else self.it.session.config.idx
+            for b in self.ALL_BATCHES:
+                for k, v in NumpyProtoDistributedBatch.from_proto_batch(b, seeds)._asdict().items():
+                    columns[k].append(v)
+            for k, lst in columns.items():
+                data_collector.np_savez_list(data_collector.get_epoch_data_filepath(k, use_rank=True), lst)
+            self.ALL_BATCHES = []
+        return None
 
     def quiesce(self):
         """See fast_sampler.Session.quiesce: drain what the native exchange has in flight before the

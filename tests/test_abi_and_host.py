@@ -155,6 +155,22 @@ def test_adj_mapping_and_batch_records():
     assert proto.get_num_local_nodes(0) == 2 and proto.get_num_communicated_nodes(0) == 1
     assert proto.idx_range == slice(0, 2)
 
+    # the statistics form of the batch (reference samplers.py:167-196) and the timer hook (transferers.py:13-18)
+    from salient_plusplus_amd.fast_trainer import transferers as tr
+    from salient_plusplus_amd.fast_trainer.samplers import NumpyProtoDistributedBatch
+    assert NumpyProtoDistributedBatch._fields == ("partition_nids", "cache_specific_nids", "perm_partition_to_mfg", "adjs", "seed_indices")
+    npb = NumpyProtoDistributedBatch.from_proto_batch(proto, torch.tensor([40, 41, 42]))
+    assert [a.tolist() for a in npb.partition_nids] == [[1, 2], [7]] and npb.seed_indices.tolist() == [40, 41]
+    assert npb.adjs[0].shape == (2, 3) and npb.adjs[0].indptr.tolist() == [0, 2, 3] and npb.adjs[0].indices.tolist() == [0, 2, 1]
+
+    class Tick:
+        name = "stage"
+        nanos = 5
+    tr.aggregate_time_results.clear()
+    tr.aggregate_time(Tick); tr.aggregate_time(Tick)
+    assert tr.aggregate_time_results == {"stage": 10}
+    tr.aggregate_time_results.clear()
+
 
 def test_shufflers_follow_reference_seeding():
     from salient_plusplus_amd.fast_trainer.shufflers import DistributedShuffler, Shuffler

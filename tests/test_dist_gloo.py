@@ -105,6 +105,7 @@ class OracleProtoIter:
         self.session.config = cfg
         self.session.group_size = group_size        # batches exchanged together (one set of collectives per group)
         self.expected = []
+        self.protos = []
 
     def __iter__(self):
         return self
@@ -122,11 +123,12 @@ class OracleProtoIter:
         adjs = [self.Adj((T(h.rowptr), T(h.col), e_id, h.size)) for h in m.hops]
         y = T(g["y"][m.n_id[:stop - start]]).unsqueeze(-1)
         self.expected.append(m.n_id)
-        return self.Proto(partition_nids=[T(a) for a in p.partition_nids],
+        self.protos.append(self.Proto(partition_nids=[T(a) for a in p.partition_nids],
                           sliced_cpu_features=torch.empty((0, g["x"].shape[1]), dtype=torch.float16),
                           sliced_cpu_labels=y, cached_nids=T(p.cached_nids),
                           perm_partition_to_mfg=T(p.perm_partition_to_mfg), adjs=adjs,
-                          idx_range=slice(start, stop), n_id=T(m.n_id))
+                          idx_range=slice(start, stop), n_id=T(m.n_id)))
+        return self.protos[-1]
 
 
 def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q, ref_shaped=False):
@@ -157,6 +159,26 @@ def _worker(rank, port, use_cache, pipeline_on, n_batches, group_size, fail_q, r
             got += 1
         assert got == n_batches
         assert devit.NUMBER_OF_SENT_BYTES > 0
+        # the driver's end-of-epoch statistics hook (reference transferers.py:843-887): off by default
+        assert devit.collect_data(None) is None
+
+        class Collector:
+            saved = {}
+
+            def get_epoch_data_filepath(self, name, use_rank=True):
+                return name
+
+            def np_savez_list(self, f, lst):
+                self.saved[f] = lst
+        devit.ALL_BATCHES = it.protos[:2]
+        assert devit.collect_data(Collector(), ids=torch.from_numpy(np.asarray(it.idx)), save_all_batch_data_to_disk=True) is None
+        kept = Collector.saved
+        assert sorted(kept) == sorted(["partition_nids", "cache_specific_nids", "perm_partition_to_mfg", "adjs", "seed_indices"])
+        assert len(kept["adjs"]) == min(2, n_batches) and len(kept["adjs"][0]) == len(SIZES)
+        first = it.protos[0]
+        np.testing.assert_array_equal(kept["perm_partition_to_mfg"][0], first.perm_partition_to_mfg.numpy())
+        np.testing.assert_array_equal(kept["seed_indices"][0], np.asarray(it.idx)[first.idx_range])
+        assert kept["adjs"][0][0].shape == tuple(first.adjs[0].adj_t.sparse_sizes())
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
