@@ -3,7 +3,10 @@
 hypothesis draws the cases (derandomised: the same ones every run); what varies is what the hand-written cases of
 test_gpu_edge_cases.py / test_gpu_pipeline.py fix: the degree distribution (isolated vertices, rows at, just below and far
 above every fan-out, a few hubs that collect a large share of a hop's edges -> bucket regions overflow), duplicated seeds,
-ragged last batches, fast (<= 32) / generic (-1, > 32) hops mixed, one to several sampling groups in flight."""
+ragged last batches, fast (<= 32) / generic (-1, > 32) hops mixed, one to several sampling groups in flight.
+SPP_FUZZ_EXAMPLES=<n> runs more cases, SPP_FUZZ_RANDOM=1 draws fresh ones (tools/fuzz_long.sh)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +18,8 @@ from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E
 
 T = torch.from_numpy
 FANOUTS = [[15, 10, 5], [5, 5], [3], [32], [1, 1, 1, 1], [20, 20, 20], [25, 15], [0, 4], [33], [-1], [4, -1], [2, 40]]
+EXAMPLES = int(os.environ.get("SPP_FUZZ_EXAMPLES", "64"))
+DERANDOMIZE = os.environ.get("SPP_FUZZ_RANDOM", "0") != "1"
 
 
 @pytest.fixture(scope="module")
@@ -39,12 +44,16 @@ def _graph(rng, n, mean_deg, zero_frac, n_hubs, hub_share):
     return rowptr, col
 
 
-@settings(max_examples=64, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(40, 6000), mean_deg=st.floats(0.5, 40.0), zero_frac=st.floats(0.0, 0.5),
        n_hubs=st.integers(0, 3), hub_share=st.floats(0.0, 0.6), sizes=st.sampled_from(FANOUTS), bs=st.sampled_from([1, 7, 64, 256, 1024]),
        n_batches=st.integers(1, 9), slots=st.sampled_from([1, 2, 5, 16, 64]), dup=st.booleans())
 def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs, n_batches, slots, dup):
     from oracle import oracle as orc
+    if os.environ.get("SPP_FUZZ_LOG"):          # the case about to run: the last line names the one that hung or crashed
+        with open(os.environ["SPP_FUZZ_LOG"], "a") as f:
+            f.write(repr(dict(seed=seed, n=n, mean_deg=mean_deg, zero_frac=zero_frac, n_hubs=n_hubs, hub_share=hub_share, sizes=sizes,
+                              bs=bs, n_batches=n_batches, slots=slots, dup=dup)) + "\n")
     rng = np.random.default_rng(seed)
     rowptr, col = _graph(rng, n, mean_deg, zero_frac, n_hubs, hub_share)
     n_idx = max(1, min(bs * n_batches - int(rng.integers(0, bs)), 4 * n))
