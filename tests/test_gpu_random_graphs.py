@@ -92,3 +92,69 @@ def test_larger_random_graph_with_hubs_against_the_oracle(fs, k):
     test_random_graph_against_the_oracle.hypothesis.inner_test(
         fs, seed=1000 + k, n=20_000, mean_deg=12.0 + k, zero_frac=0.05, n_hubs=3, hub_share=0.4, sizes=FANOUTS[k], bs=512,
         n_batches=5, slots=16, dup=bool(k & 1))
+
+
+@settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(30, 4000), mean_deg=st.floats(0.5, 45.0), zero_frac=st.floats(0.0, 0.5),
+       gen_seed=st.integers(0, 2**32 - 1),
+       calls=st.lists(st.one_of(st.tuples(st.just("adj"), st.sampled_from([-1, 0, 1, 4, 15, 32, 33, 50]), st.booleans(), st.integers(1, 700)),
+                                st.tuples(st.just("multi"), st.sampled_from(FANOUTS), st.just(False), st.integers(1, 300))), min_size=1, max_size=5))
+def test_free_functions_random_call_sequences(fs, seed, n, mean_deg, zero_frac, gen_seed, calls):
+    """sample_adj / multilayer_sample (fast_sampler.cpp:1339-1350) draw from ONE per-thread generator: a random sequence of calls
+    (fan-outs incl. all-neighbour and > 32, with and without replacement, duplicated seeds) against the oracle fed by one
+    std::mt19937 through the same sequence."""
+    from oracle import oracle as orc
+    from salient_plusplus_amd.fast_sampler import _gen
+    rng = np.random.default_rng(seed)
+    rowptr, col = _graph(rng, n, mean_deg, zero_frac, 0, 0.0)
+    _gen.seed, _gen.pos = gen_seed, 0
+    mt = orc.MT.seeded(gen_seed)
+    rp, cl = T(rowptr), T(col)
+    for kind, arg, replace, n_seeds in calls:
+        idx = rng.integers(0, n, n_seeds).astype(np.int64)
+        if kind == "adj":
+            got = fs.sample_adj(rp, cl, T(idx), arg, replace)
+            want = orc.sample_adj(rowptr, col, idx, arg, replace, mt)
+            np.testing.assert_array_equal(got[0].cpu().numpy(), want.hops[0].rowptr)
+            np.testing.assert_array_equal(got[1].cpu().numpy(), want.hops[0].col)
+            np.testing.assert_array_equal(got[2].cpu().numpy().astype(np.int64), want.n_id)
+        else:
+            n_id, adjs = fs.multilayer_sample(T(idx), list(arg), rp, cl)
+            want = orc.multilayer_sample(rowptr, col, idx, arg, mt)
+            np.testing.assert_array_equal(n_id.cpu().numpy(), want.n_id)
+            assert len(adjs) == len(want.hops)
+            for (r_, c_, _e, sz), hop in zip(adjs, want.hops):
+                np.testing.assert_array_equal(r_.cpu().numpy(), hop.rowptr)
+                np.testing.assert_array_equal(c_.cpu().numpy(), hop.col)
+                assert tuple(sz) == tuple(hop.size)
+
+
+@settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 100_000), P=st.integers(1, 9), empty=st.integers(0, 2), n_probe=st.integers(0, 5000),
+       cache_frac=st.sampled_from([0.0, 0.001, 0.1, 1.0]), on_gpu=st.booleans())
+def test_partition_book_and_cache_lookups_random(fs, seed, n, P, empty, n_probe, cache_frac, on_gpu):
+    """RangePartitionBook (range_partition_book.cpp:85-112) and Cache (:116-195) lookups over random range tables (incl. empty
+    partitions), probe lists (incl. empty ones, host and device tensors) and cached sets from none to every remote vertex."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    off = np.concatenate([[0], np.sort(rng.integers(0, n + 1, P - 1)), [n]]).astype(np.int64)
+    for _ in range(min(empty, P - 1)):
+        k = int(rng.integers(1, P))
+        off[k] = off[k - 1]
+    off = np.maximum.accumulate(off)
+    rank = int(rng.integers(0, P))
+    probe = rng.integers(0, n, n_probe).astype(np.int64)
+    pb = fs.RangePartitionBook(rank, P, T(off))
+    tp = T(probe).cuda() if on_gpu else T(probe)
+    np.testing.assert_array_equal(pb.nid2partid(tp).cpu().numpy(), orc.nid2partid(off, probe))
+    part = int(rng.integers(0, P))
+    inside = probe[(probe >= off[part]) & (probe < off[part + 1])]
+    np.testing.assert_array_equal(pb.nid2localnid(T(inside), part).cpu().numpy(), orc.nid2localnid(off, inside, part))
+    np.testing.assert_array_equal(pb.partid2nids(part).cpu().numpy(), np.arange(off[part], off[part + 1]))
+    remote = np.setdiff1d(np.arange(n), np.arange(off[rank], off[rank + 1]))
+    cv = np.sort(rng.choice(remote, size=int(round(cache_frac * remote.size)), replace=False)).astype(np.int64)
+    cache = fs.Cache(rank, P, T(cv), torch.zeros((cv.size, 2), dtype=torch.float16))
+    ocache = orc.Cache(cv, n)
+    np.testing.assert_array_equal(cache.nid_is_cached(tp).cpu().numpy().astype(bool), ocache.nid_is_cached(probe))
+    hit = probe[ocache.nid_is_cached(probe)]
+    np.testing.assert_array_equal(cache.nid2cachenid(T(hit)).cpu().numpy(), ocache.nid2cachenid(hit))
