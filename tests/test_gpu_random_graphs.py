@@ -158,3 +158,53 @@ def test_partition_book_and_cache_lookups_random(fs, seed, n, P, empty, n_probe,
     np.testing.assert_array_equal(cache.nid_is_cached(tp).cpu().numpy().astype(bool), ocache.nid_is_cached(probe))
     hit = probe[ocache.nid_is_cached(probe)]
     np.testing.assert_array_equal(cache.nid2cachenid(T(hit)).cpu().numpy(), ocache.nid2cachenid(hit))
+
+
+@settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(40, 5000), mean_deg=st.floats(0.5, 35.0), sizes=st.sampled_from(FANOUTS),
+       bs=st.sampled_from([1, 3, 50, 256, 1024]), n_idx=st.integers(1, 4000), skip=st.booleans(), force=st.booleans(), exact=st.integers(1, 12),
+       slots=st.sampled_from([1, 3, 16, 64]), xdt=st.sampled_from(["float16", "float32", "int64", "uint8"]), F=st.sampled_from([1, 3, 16, 100, 128]),
+       x_on_gpu=st.booleans(), with_y=st.booleans(), epochs=st.integers(1, 2))
+def test_random_facade_configurations(fs, seed, n, mean_deg, sizes, bs, n_idx, skip, force, exact, slots, xdt, F, x_on_gpu, with_y, epochs):
+    """The façade (FastSamplerConfig -> FastSampler -> DevicePrefetcher; samplers.py:213-399, transferers.py:890-970) over random
+    batch-range options (skip_nonfull_batch, force_exact_num_batches: fast_sampler.cpp:587-627), feature dtypes and widths, the
+    feature matrix handed over as a host or a device tensor, with and without labels, and a second epoch with new seeds on the
+    same sampler: x = features[n_id], y = labels[n_id[:batch]], the MFG bit for bit."""
+    from oracle import oracle as orc
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+    from salient_plusplus_amd.fast_trainer.transferers import DevicePrefetcher
+    rng = np.random.default_rng(seed)
+    rowptr, col = _graph(rng, n, mean_deg, 0.1, 0, 0.0)
+    x = rng.integers(0, 250, (n, F)).astype(xdt)
+    y = rng.integers(0, 40, n).astype(np.int64)
+    if force:
+        n_idx = max(n_idx, exact)              # at least one seed per batch
+    dev = torch.device("cuda", 0)
+    cfg = FastSamplerConfig(
+        x_cpu=T(x).cuda() if x_on_gpu else T(x), x_gpu=torch.empty(0), y=T(y).unsqueeze(-1) if with_y else None, rowptr=T(rowptr), col=T(col),
+        idx=T(rng.integers(0, n, n_idx).astype(np.int64)), batch_size=bs, sizes=list(sizes), skip_nonfull_batch=skip, pin_memory=False,
+        distributed=False, partition_book=None, cache=fs.Cache(), force_exact_num_batches=force, exact_num_batches=exact,
+        count_remote_frequency=False, use_cache=False)
+    sampler = FastSampler(2, slots, cfg)
+    for epoch in range(epochs):
+        if epoch:
+            sampler.idx = T(rng.integers(0, n, n_idx).astype(np.int64))
+        idx = sampler.idx.numpy()
+        ranges = orc.batch_ranges(len(idx), bs, skip, force, exact)
+        assert len(sampler) == len(ranges)
+        got = [b for (b,) in DevicePrefetcher([dev], iter(sampler))]
+        assert len(got) == len(ranges)
+        for b, (r0, r1) in zip(got, ranges):
+            assert (b.idx_range.start, b.idx_range.stop) == (int(r0), int(r1))
+            m = orc.sample_batch(rowptr, col, idx, int(r0), int(r1), sizes)
+            assert b.x.dtype == T(x[:0]).dtype
+            np.testing.assert_array_equal(b.x.cpu().numpy(), x[m.n_id])
+            if with_y:
+                np.testing.assert_array_equal(b.y.cpu().numpy().reshape(-1), y[m.n_id[:int(r1) - int(r0)]])
+            else:
+                assert b.y is None
+            for adj, hop in zip(b.adjs, m.hops):
+                rp, cl, _ = adj.adj_t.csr()
+                np.testing.assert_array_equal(rp.cpu().numpy(), hop.rowptr)
+                np.testing.assert_array_equal(cl.cpu().numpy(), hop.col)
+                assert tuple(adj.size) == (hop.size[1], hop.size[0])

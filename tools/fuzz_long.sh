@@ -12,6 +12,9 @@ for r in $(seq 1 $rounds); do
   echo "round $r session, free functions, lookups: $(grep -o '[0-9]* passing' "$out/fuzz_session_$r.txt" | tr '\n' ' ')"
   SPP_FUZZ_LOG="$out/cases_exchange.log" SPP_FUZZ_RANDOM=1 SPP_FUZZ_EXAMPLES=$m timeout -k 10 300 python3 -m pytest tests/test_gpu_random_exchange.py -x -q -m gpu \
     -p no:cacheprovider --hypothesis-show-statistics > "$out/fuzz_exchange_$r.txt" 2>&1 || { tail -60 "$out/fuzz_exchange_$r.txt"; tail -1 "$out/cases_exchange.log"; exit 1; }
+  SPP_FUZZ_RANDOM=1 SPP_FUZZ_EXAMPLES=$m timeout -k 10 600 python3 -m pytest tests/test_gpu_random_graphs.py -x -q -m gpu -p no:cacheprovider \
+    -k test_random_facade_configurations --hypothesis-show-statistics > "$out/fuzz_facade_$r.txt" 2>&1 || { tail -60 "$out/fuzz_facade_$r.txt"; exit 1; }
+  echo "round $r facade: $(grep -o '[0-9]* passing' "$out/fuzz_facade_$r.txt")"
   echo "round $r exchange: $(grep -o '[0-9]* passing' "$out/fuzz_exchange_$r.txt")"
   SPP_FUZZ_RANDOM=1 SPP_FUZZ_EXAMPLES=$n timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -p no:cacheprovider \
     -k test_gather_rows_random_shapes --hypothesis-show-statistics > "$out/fuzz_gather_$r.txt" 2>&1 || { tail -40 "$out/fuzz_gather_$r.txt"; exit 1; }
