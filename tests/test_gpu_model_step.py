@@ -397,3 +397,38 @@ def test_sage_random_mfg_chains_match_plain_torch(seed, layers, t_last, grow, ma
     for i in range(layers):
         torch.testing.assert_close(hip.convs[i].lin_l.weight.grad, ref.lin_l[i].weight.grad, rtol=1e-3, atol=1e-5)
         torch.testing.assert_close(hip.convs[i].lin_r.weight.grad, ref.lin_r[i].weight.grad, rtol=1e-3, atol=1e-5)
+
+
+@settings(max_examples=int(os.environ.get("SPP_FUZZ_EXAMPLES", "40")), deadline=None,
+          derandomize=os.environ.get("SPP_FUZZ_RANDOM", "0") != "1", suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(0, 2**31 - 1), T=st.integers(1, 600), extra=st.integers(0, 2000), maxdeg=st.integers(0, 15),
+       F=st.sampled_from([1, 8, 47, 100, 256]), diag=st.booleans())
+def test_gat_aggregate_random_hops(seed, T, extra, maxdeg, F, diag):
+    """The fused GAT aggregation (self loops added, diagonal entries dropped, edge softmax, weighted sum) against plain torch on
+    randomly drawn hops: a single target, all-empty rows, hops that contain their own diagonal; forward 1e-4, gradients 1e-3."""
+    from salient_plusplus_amd.models import _GatAggregate
+    g = torch.Generator().manual_seed(seed)
+    S = T + extra
+    deg = torch.randint(0, maxdeg + 1, (T,), generator=g)
+    rowptr = torch.zeros(T + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(deg, 0)
+    col = torch.randint(0, S, (int(rowptr[-1]),), generator=g)
+    if diag and col.numel():
+        col[::5] = torch.repeat_interleave(torch.arange(T), deg)[::5]
+    rowptr, col = rowptr.cuda(), col.cuda()
+    h0 = torch.randn((S, F), generator=g).cuda()
+    as0 = torch.randn(S, generator=g).cuda()
+    ad0 = torch.randn(T, generator=g).cuda()
+    row = torch.repeat_interleave(torch.arange(T, device="cuda"), rowptr[1:] - rowptr[:-1])
+    e_all = torch.cat([as0[col] + ad0[row], as0[:T] + ad0])
+    hyp.assume(float(e_all.abs().min()) > 1e-6)             # a logit at the leaky-ReLU kink may take either slope
+    ins_a = [t.clone().requires_grad_(True) for t in (h0, as0, ad0)]
+    ins_b = [t.clone().requires_grad_(True) for t in (h0, as0, ad0)]
+    out_a = _GatAggregate.apply(ins_a[0], ins_a[1], ins_a[2], rowptr, col, 0.2)
+    out_b = _ref_gat(ins_b[0], ins_b[1], ins_b[2], rowptr, col, T)
+    torch.testing.assert_close(out_a, out_b, rtol=1e-4, atol=1e-5)
+    w = torch.randn((T, F), generator=g).cuda()
+    (out_a * w).sum().backward()
+    (out_b * w).sum().backward()
+    for a, b in zip(ins_a, ins_b):
+        torch.testing.assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-4)
