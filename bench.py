@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--fanouts", default="",
                     help="comma-separated fan-outs instead of the workload's own (e.g. 20,20,20: the reference's batchwise "
                          "inference; a hop < 0 or > 32 takes the generic sampling path: one batch per launch, a host sync per hop)")
+    ap.add_argument("--no-fused-leg", action="store_true",
+                    help="N=1, SAGE: skip the model-step leg of the opt-in fused consumer (Session(table_features) + "
+                         "models.SAGE reading its first layer straight from the resident feature table)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="launcher only: print the GPU count found without the HIP runtime and whether libamdhip64 is mapped "
                          "into the launcher process, start nothing")
@@ -707,6 +710,15 @@ def main():
                           f"{torch.cuda.memory_reserved(dev) / 2**30:.1f} GB, free HBM {torch.cuda.mem_get_info(dev)[0] / 2**30:.1f} GB",
                           file=sys.stderr, flush=True)
         ts = time.perf_counter()
+        if os.environ.get("SPP_BENCH_TAIL") == "1":   # diagnostic: how long the closing synchronize waits for the DELIVERIES
+            side = getattr(getattr(feeder.devit, "side", None), "stream", None)     # and how long for the chains behind them
+            if side is not None:
+                side.synchronize()
+            torch.cuda.current_stream().synchronize()
+            t_del = time.perf_counter()
+            torch.cuda.synchronize()
+            print(f"[bench] window {_w}: issue {1e6 * (ts - t0):.0f} us, deliveries done +{1e6 * (t_del - ts):.0f} us, "
+                  f"everything else (chains in flight) +{1e6 * (time.perf_counter() - t_del):.0f} us", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         if step_t is not None:                    # diagnostic: host time of every step of a window, and of its closing synchronize
             shown = step_t if len(step_t) <= 24 else sorted(step_t)[-8:]
@@ -791,6 +803,29 @@ def main():
                                         "batches_per_epoch_and_rank": nb_epoch,
                                         "ms_per_step_model_only_resident_batch": m_only,
                                         "ms_per_step_with_data_path": m_data, "timing": m_detail}}
+            if not distributed and a.model == "sage" and not a.no_fused_leg:
+                # Row g1: the opt-in fused consumer.  The Session delivers MFG + labels + n_id and NO feature rows
+                # (PreparedBatch.x = TableRows(resident table, n_id)); models.SAGE's first layer aggregates straight from
+                # the table (bit-identical operand, tests/test_gpu_model_step.py).  Same model, same optimiser, same
+                # windows as the default legs above, which stay the ones `epoch_time_s_with_model_step` is quoted on.
+                feeder.devit = None                   # the default Session ends: its pooled sampler serves the next one
+                gc.collect()
+                fused_sampler = FastSampler(4, a.slots, cfg, table_features=True)
+
+                def make_fused_iter(idx):
+                    fused_sampler.idx = idx
+                    return DevicePrefetcher([dev], iter(fused_sampler))
+                fused_feeder = EpochFeeder(make_fused_iter, shuffler, shuffler.get_idx)
+                f_only, f_data, f_detail = model_step_timing(fused_feeder, F, 47, hip=True, arch=a.model)
+                fused_feeder.devit = None
+                gc.collect()
+                model_out["model_step"]["fused_first_layer"] = {
+                    "what": "Session(table_features): no x gather in the delivery, SAGE layer 1 reads table[n_id[j]] itself "
+                            "(spp_sage_operand_forward_table)",
+                    "ms_per_step_model_only_resident_batch": f_only, "ms_per_step_with_data_path": f_data,
+                    "data_path_cost_ms": f_data - f_only, "epoch_time_s_with_model_step": nb_epoch * f_data / 1e3,
+                    "timing": f_detail}
+                model_out["model_step"]["data_path_cost_ms"] = m_data - m_only
             if not distributed:
                 t_only, t_data, _ = model_step_timing(feeder, F, 47, hip=False, windows=2, warm=4)
                 model_out["model_step"]["plain_torch_formulation"] = {
@@ -826,8 +861,13 @@ def main():
         # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
         # (the partitioned path's delivery -- assembly from {local, received, cache} rows -- has a pass of its own)
-        pmc_files = ("r03_deliver_partitioned_pmc.json",) if distributed else \
-            ("r03_deliver_pmc_papers.json", "r02_deliver_pmc_papers.json", "r01_gather_pmc_papers.json", "r01_gather_pmc.json")
+        import glob
+        prof_dir = os.path.join(ROOT, "profiles")
+
+        def newest_first(pattern):
+            return tuple(os.path.basename(f) for f in sorted(glob.glob(os.path.join(prof_dir, pattern)), reverse=True))
+        pmc_files = newest_first("r0?_deliver_partitioned_pmc.json") if distributed else \
+            newest_first("r0?_deliver_pmc_*.json") + newest_first("r0?_gather_pmc_papers.json") + newest_first("r0?_gather_pmc.json")
         for pmc_name in pmc_files:
             pmc_path = os.path.join(ROOT, "profiles", pmc_name)
             if (distributed and not native) or not os.path.exists(pmc_path):

@@ -63,7 +63,11 @@ spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64
 
 /* Run-time tuning knobs (measurement aid and the hook of embedders that pace the data path themselves).
  * "gather_wg_per_cu": workgroups per compute unit a row gather / delivery launch may put on the chip (default 16, or
- * SPP_GATHER_WG_PER_CU); value <= 0 only reads.  Returns the previous value, or a negative spp_status. */
+ * SPP_GATHER_WG_PER_CU); value <= 0 only reads.
+ * "gather_span": 1 (default; SPP_GATHER_SPAN=0) = rows of 16k + 8 bytes (200-byte rows of 100 fp16 features) out of a
+ * table whose base and row stride are multiples of 16 bytes (>= the row + 8) into a 16-byte-aligned destination are moved
+ * with 16-byte accesses (the loads read up to 8 bytes of the row's padding; never written); 0 = the 8-byte form;
+ * value < 0 only reads.  Returns the previous value, or a negative spp_status. */
 int spp_tune(const char* key, int value);
 
 /* Asynchronously detected data errors.  The reference's CPU code does not range-check row indices
@@ -470,6 +474,16 @@ spp_status spp_csr_mean_backward(const int64_t* rowptr_dev, const int64_t* col_d
 spp_status spp_sage_operand_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                     const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
                                     float* out_dev, int64_t out_stride_elems /* >= 2F */, void* stream);
+/* The same operand straight from the RESIDENT feature table (opt-in consumer of the data path, DESIGN section 5
+ * "fused first layer"): row j of the batch is table[n_id[j]] (n_id int64 [S], the batch's node ids as the Session
+ * delivers them; table rows table_stride_elems apart, fp16 or fp32), so the batch's feature matrix x = table[n_id]
+ * (fast_sampler.cpp:1004-1016 `x = serial_index(x_cpu, n_id)`) is never written and read back -- the rows are summed
+ * in the same order as spp_sage_operand_forward sums the rows of a materialised x: the operand is bit-identical.
+ * An id outside [0, table_rows) reads row 0. */
+spp_status spp_sage_operand_forward_table(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                          const void* table_dev, int32_t table_is_half, int64_t table_stride_elems,
+                                          int64_t table_rows, const int64_t* n_id_dev, int64_t F, float* out_dev,
+                                          int64_t out_stride_elems /* >= 2F */, void* stream);
 /* Its backward: grad_x [S, F] is written completely -- rows < T start from the gradient of the x_target
  * half, the others from zero, then the mean's gradient is scattered on top (fp32 atomics). */
 spp_status spp_sage_operand_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,

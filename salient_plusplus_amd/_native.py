@@ -118,6 +118,7 @@ SIGNATURES = {
     "spp_csr_mean_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
     "spp_csr_mean_backward": (C.c_int, [p, p, i64, p, i64, i64, p, p]),
     "spp_sage_operand_forward": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p]),
+    "spp_sage_operand_forward_table": (C.c_int, [p, p, i64, p, i32, i64, i64, p, i64, p, i64, p]),
     "spp_sage_operand_backward": (C.c_int, [p, p, i64, i64, p, i64, i64, p, p]),
     "spp_sage_operand_backward_workspace_bytes": (i64, [i64, i64, i64]),
     "spp_sage_operand_backward_gather": (C.c_int, [p, p, i64, i64, i64, p, i64, i64, p, p, i64, p]),

@@ -65,12 +65,17 @@ __device__ __forceinline__ f4 relu_dropout4(f4 v, int64_t i4, const ActArgs& a) 
 // kAct (fp32, VEC4, dense rows: x_stride == F): x is a PRE-activation; relu + dropout are applied to every row
 // as it is loaded -- the same values a k_relu_dropout_fwd pass over x would have produced (same generator,
 // same element indices), without the pass.
-template <typename Tin, bool VEC4, bool kAct = false>
+// kTable (first layer, opt-in): x is the RESIDENT feature table and row j of the batch is x[nid[j]] (nid = the batch's
+// n_id, int64) -- the batch's feature matrix is never written and re-read (242 MB each way at papers scale); the sum
+// runs over the same rows in the same order as over a materialised x[n_id], so the operand is bit-identical.  An id
+// outside [0, x_rows) reads row 0 (no fault).
+template <typename Tin, bool VEC4, bool kAct = false, bool kTable = false>
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
                                                          const Tin* __restrict__ x, int64_t x_stride, int64_t F,
                                                          int lpr_log2, float* __restrict__ out, int64_t out_stride,
-                                                         int concat_target, ActArgs act) {
+                                                         int concat_target, ActArgs act,
+                                                         const int64_t* __restrict__ nid = nullptr, int64_t x_rows = 0) {
   const int lpr = 1 << lpr_log2;
   const int lane = threadIdx.x & (lpr - 1);
   const int64_t t = ((int64_t)blockIdx.x * kAggNT + threadIdx.x) >> lpr_log2;
@@ -78,6 +83,10 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
   const int64_t b = rowptr[t], e = rowptr[t + 1];
   const float inv = 1.0f / (float)(e > b ? e - b : 1);
   auto row4 = [&](int64_t j, int64_t c) {  // four columns of row j (activated on load with kAct)
+    if constexpr (kTable) {
+      const int64_t g = nid[j];
+      j = (uint64_t)g < (uint64_t)x_rows ? g : 0;
+    }
     f4 v = load4(x + j * x_stride + c);
     if constexpr (kAct) v = relu_dropout4(v, (j * x_stride + c) >> 2, act);
     return v;
@@ -103,10 +112,17 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
           make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
     }
   } else {
+    auto row_of = [&](int64_t j) {
+      if constexpr (kTable) {
+        const int64_t g = nid[j];
+        j = (uint64_t)g < (uint64_t)x_rows ? g : 0;
+      }
+      return j;
+    };
     for (int64_t c = lane; c < F; c += lpr) {
-      if (concat_target) out[t * out_stride + F + c] = load1(x + t * x_stride + c);
+      if (concat_target) out[t * out_stride + F + c] = load1(x + row_of(t) * x_stride + c);
       float acc = 0.f;
-      for (int64_t k = b; k < e; ++k) acc += load1(x + col[k] * x_stride + c);
+      for (int64_t k = b; k < e; ++k) acc += load1(x + row_of(col[k]) * x_stride + c);
       out[t * out_stride + c] = acc * inv;
     }
   }
@@ -281,7 +297,8 @@ using namespace spp;
 
 static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
-                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream);
+                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream,
+                               const int64_t* n_id_dev = nullptr, int64_t table_rows = 0);
 
 extern "C" spp_status spp_csr_mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                            const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
@@ -298,9 +315,22 @@ extern "C" spp_status spp_sage_operand_forward(const int64_t* rowptr_dev, const 
                       1, stream);
 }
 
+extern "C" spp_status spp_sage_operand_forward_table(const int64_t* rowptr_dev, const int64_t* col_dev,
+                                                     int64_t num_targets, const void* table_dev, int32_t table_is_half,
+                                                     int64_t table_stride_elems, int64_t table_rows,
+                                                     const int64_t* n_id_dev, int64_t F, float* out_dev,
+                                                     int64_t out_stride_elems, void* stream) {
+  SPP_REQUIRE(out_stride_elems >= 2 * F, "spp_sage_operand_forward_table: the operand [mean | x_target] needs 2F columns");
+  SPP_REQUIRE(num_targets == 0 || (n_id_dev && table_dev && table_rows > 0),
+              "spp_sage_operand_forward_table: needs the feature table and the batch's node ids");
+  return mean_forward(rowptr_dev, col_dev, num_targets, table_dev, table_is_half, table_stride_elems, F, out_dev,
+                      out_stride_elems, 1, stream, n_id_dev, table_rows);
+}
+
 static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
                                const void* x_dev, int32_t x_is_half, int64_t x_stride_elems, int64_t F,
-                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream) {
+                               float* out_dev, int64_t out_stride_elems, int concat_target, void* stream,
+                               const int64_t* n_id_dev, int64_t table_rows) {
   SPP_REQUIRE(num_targets >= 0 && F >= 0, "spp_csr_mean_forward: negative size");
   if (num_targets == 0 || F == 0) return SPP_OK;
   SPP_REQUIRE(rowptr_dev && out_dev, "spp_csr_mean_forward: NULL buffer");
@@ -314,10 +344,17 @@ static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev
                    (reinterpret_cast<uintptr_t>(out_dev) % 16 == 0) && (out_stride_elems % 4 == 0);
   const int lpr_log2 = lanes_log2(vec ? F / 4 : F);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
-#define SPP_AGG(TIN, V)                                                                                          \
-  hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, \
-                     static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems,   \
-                     concat_target, ActArgs{})
+#define SPP_AGG(TIN, V)                                                                                               \
+  do {                                                                                                                \
+    if (n_id_dev)                                                                                                     \
+      hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V, false, true>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, \
+                         num_targets, static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev,           \
+                         out_stride_elems, concat_target, ActArgs{}, n_id_dev, table_rows);                           \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_csr_mean_fwd<TIN, V>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev, num_targets, \
+                         static_cast<const TIN*>(x_dev), x_stride_elems, F, lpr_log2, out_dev, out_stride_elems,      \
+                         concat_target, ActArgs{}, nullptr, (int64_t)0);                                              \
+  } while (0)
   if (x_is_half) {
     if (vec) SPP_AGG(__half, true); else SPP_AGG(__half, false);
   } else {
@@ -350,7 +387,8 @@ extern "C" spp_status spp_sage_operand_forward_act(const int64_t* rowptr_dev, co
   const int lpr_log2 = lanes_log2(F / 4);
   const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
   hipLaunchKernelGGL((k_csr_mean_fwd<float, true, true>), dim3(grid), dim3(kAggNT), 0, as_stream(stream), rowptr_dev,
-                     col_dev, num_targets, x_dev, F, F, lpr_log2, out_dev, out_stride_elems, 1, act_args(p, training, seed));
+                     col_dev, num_targets, x_dev, F, F, lpr_log2, out_dev, out_stride_elems, 1, act_args(p, training, seed),
+                     nullptr, (int64_t)0);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -58,6 +58,17 @@ int gather_wg_per_cu() {
   return v;
 }
 
+static std::atomic<int> g_gather_span{-1};       // -1: not read from the environment yet
+bool gather_span_enabled() {
+  int v = g_gather_span.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("SPP_GATHER_SPAN");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+    g_gather_span.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 // ---- asynchronously detected data errors (spp_async_errors) ----
 static std::mutex g_aerr_mu;
 static int32_t* g_aerr[64] = {};
@@ -128,6 +139,11 @@ int spp_tune(const char* key, int value) {
   if (!strcmp(key, "gather_wg_per_cu")) {
     const int prev = spp::gather_wg_per_cu();
     if (value > 0) spp::g_gather_wg_per_cu.store(value, std::memory_order_relaxed);
+    return prev;
+  }
+  if (!strcmp(key, "gather_span")) {  // 16-byte span form of the row gather for rows of 16k + 8 bytes (value < 0: query)
+    const int prev = spp::gather_span_enabled() ? 1 : 0;
+    if (value >= 0) spp::g_gather_span.store(value ? 1 : 0, std::memory_order_relaxed);
     return prev;
   }
   spp::set_error("spp_tune: unknown knob '%s'", key);

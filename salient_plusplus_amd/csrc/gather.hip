@@ -24,7 +24,7 @@ static spp_status launch_gather(const void* src, int64_t src_rows, int64_t row_b
                                 const IdxT* idx, int64_t n, void* dst, hipStream_t st) {
   if (n <= 0 || row_bytes <= 0) return SPP_OK;
   if (src_stride <= 0) src_stride = row_bytes;
-  const GatherGeom gg = gather_geometry(src, dst, row_bytes, n, src_stride);
+  const GatherGeom gg = gather_geometry(src, dst, row_bytes, n, src_stride, /*allow_span=*/true);
   const int chunks = gg.chunks, lpr_log2 = gg.lpr_log2;
   const int64_t grid = gg.grid;
   const char* s = static_cast<const char*>(src);
@@ -42,6 +42,7 @@ static spp_status launch_gather(const void* src, int64_t src_rows, int64_t row_b
                          src_rows, idx, n, row_bytes, chunks, lpr_log2, d, src_stride, err);                    \
   } while (0)
   switch (gg.vec) {
+    case kVecSpan: SPP_LAUNCH_GATHER(kVecSpan); break;
     case 16: SPP_LAUNCH_GATHER(16); break;
     case 8: SPP_LAUNCH_GATHER(8); break;
     case 4: SPP_LAUNCH_GATHER(4); break;

@@ -2713,7 +2713,8 @@ static spp_status fill_deliver_args(spp_sampler* s, int slot, const spp_mfg_out*
     if (asrc)
       align_probe |= reinterpret_cast<uintptr_t>(asrc->recv) | reinterpret_cast<uintptr_t>(asrc->cache) |
                      (uintptr_t)a.cache_stride;
-    const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U, x_src_stride);
+    const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U, x_src_stride,
+                                          /*allow_span=*/!asrc);  // (received rows are dense: no padding to read into)
     a.x_src_stride = x_src_stride;
     vec = gg.vec;
     a.x_src = static_cast<const char*>(x_src);
@@ -2748,6 +2749,7 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   if (grid == 0) return SPP_OK;
   const int prof = prof_begin(SPP_PROF_GATHER, st, a.x_rows);
   switch (vec) {
+    case kVecSpan: hipLaunchKernelGGL(k_deliver<kVecSpan>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
     case 16: hipLaunchKernelGGL(k_deliver<16>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
     case 8: hipLaunchKernelGGL(k_deliver<8>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
     case 4: hipLaunchKernelGGL(k_deliver<4>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
@@ -2782,7 +2784,9 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
     int v = 16;
     SPP_TRY(fill_deliver_args(s, first_slot + i, &outs[i].mfg, x_src, x_row_bytes, x_src_stride, outs[i].x_out, y_src,
                               y_row_bytes, y_rows[i], outs[i].y_out, asrc ? &asrc[i] : nullptr, ha[i], &v));
-    vec = std::min(vec, v);
+    // (kVecSpan only when every batch of the group qualifies; otherwise such a batch runs in the 8-byte form)
+    if (i == 0) vec = v;
+    else if (vec != v) vec = std::min(vec == kVecSpan ? 8 : vec, v == kVecSpan ? 8 : v);
     gb.start[i] = (int32_t)blocks;
     blocks += ha[i].nb_x + ha[i].nb_e + ha[i].nb_y;
     rows += ha[i].x_rows;
@@ -2810,7 +2814,7 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
   // a narrower access width than a batch was laid out for: its lanes-per-row geometry follows the common width
   for (int i = 0; i < n; ++i) {
     if (ha[i].nb_x == 0) continue;
-    const int chunks = (int)(ha[i].x_row_bytes / vec);
+    const int chunks = vec == kVecSpan ? ha[i].x_chunks : (int)(ha[i].x_row_bytes / vec);
     if (chunks != ha[i].x_chunks) {
       int lpr = 0;
       while ((1 << lpr) < chunks && lpr < 6) ++lpr;
@@ -2822,6 +2826,7 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
   const int prof = prof_begin(SPP_PROF_GATHER, st, rows);
   const DeliverArgs* da = s->dargs_dev[set];
   switch (vec) {
+    case kVecSpan: hipLaunchKernelGGL(k_deliver_group<kVecSpan>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
     case 16: hipLaunchKernelGGL(k_deliver_group<16>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
     case 8: hipLaunchKernelGGL(k_deliver_group<8>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
     case 4: hipLaunchKernelGGL(k_deliver_group<4>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;

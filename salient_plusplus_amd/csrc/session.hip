@@ -340,12 +340,14 @@ static spp_status launch_serve(spp_session* s, const int32_t* ids, int64_t n, ch
   if (n <= 0) return SPP_OK;
   SPP_REQUIRE(s->xcfg.x_local_rows > 0, "exchange: peers request %lld rows but this rank owns none", (long long)n);
   int32_t* err = async_err_word(s->cfg.device);
-  const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n, s->xcfg.x_local_stride_bytes);
+  const GatherGeom gg = gather_geometry(s->xcfg.x_local_dev, out, s->xcfg.row_bytes, n, s->xcfg.x_local_stride_bytes,
+                                        /*allow_span=*/true);
   const char* x = static_cast<const char*>(s->xcfg.x_local_dev);
 #define SPP_SERVE(V)                                                                                              \
   hipLaunchKernelGGL(k_serve_rows<V>, dim3((unsigned)gg.grid), dim3(kGatherThreads), 0, st, x, s->xcfg.x_local_rows, \
                      ids, n, s->rank_offset, s->xcfg.row_bytes, s->xcfg.x_local_stride_bytes, gg.chunks, gg.lpr_log2, out, err)
   switch (gg.vec) {
+    case kVecSpan: SPP_SERVE(kVecSpan); break;
     case 16: SPP_SERVE(16); break;
     case 8: SPP_SERVE(8); break;
     case 4: SPP_SERVE(4); break;

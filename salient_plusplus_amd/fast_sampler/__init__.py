@@ -19,6 +19,7 @@ There is no CPU fallback: without the HIP extension and a GPU every entry point 
 import collections
 import ctypes as C
 import datetime
+import math
 import os
 import threading
 from typing import List, Optional, Sequence
@@ -169,6 +170,67 @@ def _as_i64_list(sizes: Sequence[int]) -> List[int]:
     if not 1 <= len(out) <= nat.SPP_MAX_HOPS:
         raise RuntimeError(f"sizes must have between 1 and {nat.SPP_MAX_HOPS} entries, got {len(out)}")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the batch's features as (resident table, node ids) -- opt-in, for a consumer that aggregates straight from the table
+# --------------------------------------------------------------------------------------------
+class TableRows:
+    """``x = table[n_id]`` without the copy: what a Session with ``table_features`` puts in the place of the batch's
+    feature matrix (fast_sampler.cpp:1004-1016 ``serial_index(x_cpu, n_id)``).  ``models.SAGE`` aggregates its first
+    layer straight from ``table`` (spp_sage_operand_forward_table: same rows, same summation order, bit-identical
+    operand), so the 242 MB of rows a papers-scale batch holds are neither written by the delivery nor read back.
+    Everything else still sees a feature matrix through ``materialize()``; sizes / device / dtype read like the
+    tensor's."""
+    __slots__ = ("table", "n_id")
+
+    def __init__(self, table: torch.Tensor, n_id: torch.Tensor):
+        self.table, self.n_id = table, n_id
+
+    # -- what iterators and records ask of a feature matrix --
+    @property
+    def is_cuda(self):
+        return self.n_id.is_cuda
+
+    @property
+    def device(self):
+        return self.n_id.device
+
+    @property
+    def dtype(self):
+        return self.table.dtype
+
+    @property
+    def shape(self):
+        return torch.Size((self.n_id.numel(), self.table.size(1)))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def numel(self):
+        return self.n_id.numel() * self.table.size(1)
+
+    def record_stream(self, stream):
+        if self.n_id.is_cuda:
+            self.n_id.record_stream(stream)              # (the table lives as long as the graph does)
+
+    def to(self, device=None, non_blocking=False, **_kw):
+        if device is None or torch.device(device) == self.n_id.device:
+            return self
+        return self.materialize().to(device=device, non_blocking=non_blocking)
+
+    def materialize(self) -> torch.Tensor:
+        """The feature matrix itself: the HIP row gather on the caller's current stream (a5, serial_index)."""
+        t = self.table                                   # (a strided view of the padded resident table)
+        out = torch.empty((self.n_id.numel(), t.size(1)), dtype=t.dtype, device=t.device)
+        if out.numel():
+            nat.check(_lib().spp_gather_rows_strided(_ptr(t), t.size(0), t.size(1) * t.element_size(), _stride_bytes(t),
+                                                     _ptr(self.n_id), 8, self.n_id.numel(), self.n_id.numel(), _ptr(out),
+                                                     _stream_ptr()))
+        return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -593,6 +655,10 @@ class Session:
         # SPP_GROUP_FETCH=0: spp_session_next / spp_session_export per batch, nine allocations each.
         self._member_mode = not self._group_mode and os.environ.get("SPP_GROUP_FETCH", "1") != "0"
         self._open = None                          # [next member, fetched group] while a group is partly handed out
+        # opt-in (single-GPU sessions): the records carry TableRows(resident table, n_id) in the place of x and the
+        # delivery launch skips the feature gather (labels + MFG + n_id are still delivered) -- for models.SAGE's
+        # fused first layer.  Set before the first batch is asked for; SPP_TABLE_FEATURES=1 sets it for every Session.
+        self.table_features = os.environ.get("SPP_TABLE_FEATURES", "0") != "0"
         self.export_stream = None                  # set by a consumer that delivers on ONE fixed stream (DevicePrefetcher): the
         self._export_raw = None                    # per-batch path then skips the current-stream lookup / stream context
         self.last_arenas = None                    # the (<= 3) storages behind the views of the batch handed out last
@@ -820,6 +886,14 @@ class Session:
             return (x, y, adjs, rng)
         return self._proto_record(x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank)
 
+    def _table_mode(self) -> bool:
+        if not self.table_features:
+            return False
+        if self._distributed or self._x is None:
+            raise RuntimeError("table_features: only single-GPU sessions with a feature table deliver TableRows "
+                               "(a partitioned session assembles x from three sources)")
+        return True
+
     def _next_member(self, block: bool):
         """The default delivery: the sampling group is FETCHED as a whole (one blocking call, one allocation per output
         kind for all its batches, the views cut once) and its batches are then delivered one launch each, when asked
@@ -873,8 +947,9 @@ class Session:
         use_cache = bool(cfg.use_cache) if distributed else False
         count_remote = distributed and bool(cfg.count_remote_frequency) and not use_cache
         want_parts = distributed and (not native or count_remote or not self.compact_native_records)
-        want_n_id = distributed
-        want_x = (self._x is not None) and (native or not distributed)
+        table = self._table_mode()
+        want_n_id = distributed or table
+        want_x = (self._x is not None) and (native or not distributed) and not table
         want_y = self._y is not None
         H = int(self._gdescs[0].counts.num_hops)
         # ---- sizes (host counts of every batch) and the arena layout
@@ -914,10 +989,17 @@ class Session:
         row_b = 0
         if want_x:
             F = self._x.size(1)
-            n_rows = sum(Us)
+            row_b = F * self._x.element_size()
+            # every batch starts on a 16-byte boundary of the arena (rows of 16k + 8 bytes: on an even row), so that the
+            # delivery may store 16-byte pieces whatever the batches before it hold (gather_body.cuh, kVecSpan)
+            x_align = 16 // math.gcd(row_b, 16)
+            x_split = []
+            for U in Us:
+                x_split += [U, (-U) % x_align]
+            n_rows = sum(x_split)
             x_arena = torch.empty((_coarse(n_rows), F), dtype=self._x.dtype, device=dev)
-            x_views = x_arena.split(Us + [x_arena.size(0) - n_rows])
-            x_base, row_b = x_arena.data_ptr(), F * self._x.element_size()
+            x_views = x_arena.split(x_split + [x_arena.size(0) - n_rows])[0::2]
+            x_base = x_arena.data_ptr()
         if want_y:
             y_arena = torch.empty((sum(bss), self._y.size(1)), dtype=self._y.dtype, device=dev)
             y_views = y_arena.split(bss)
@@ -960,10 +1042,12 @@ class Session:
                 o.mfg.perm = (base + 8 * off) if U else None
                 off += U
             x = y = None
+            if table:
+                x = TableRows(self._x, n_id)
             if want_x:
                 x = x_views[i]
                 o.x_out = (x_base + xo * row_b) if U else None
-                xo += U
+                xo += U + (-U) % x_align
             if want_y:
                 y = y_views[i]
                 o.y_out = (y_base + yo * yrow_b) if bss[i] else None
@@ -1030,16 +1114,19 @@ class Session:
             return None
         d = self._desc
         c = d.counts
-        out, _n_id, adjs = self._alloc_mfg(c, want_n_id=False)         # n_id is not part of the tuple
+        table = self._table_mode()
+        out, n_id, adjs = self._alloc_mfg(c, want_n_id=table)          # n_id is not part of the tuple
         x = y = None
-        if self._x is not None:
+        if table:
+            x = None
+        elif self._x is not None:
             x = torch.empty((c.num_nodes, self._x.size(1)), dtype=self._x.dtype, device=self._dev)
         else:
             x = torch.empty((c.num_nodes, 0), device=self._dev)
         if self._y is not None:
             y = torch.empty((d.stop - d.start, self._y.size(1)), dtype=self._y.dtype, device=self._dev)
         self._export(out, x, y)
-        return (x, y, adjs, (int(d.start), int(d.stop)))
+        return (TableRows(self._x, n_id) if table else x, y, adjs, (int(d.start), int(d.stop)))
 
     def try_get_batch(self):
         """Non-blocking (fast_sampler.cpp:658-670): None when no batch is ready yet or none is left."""

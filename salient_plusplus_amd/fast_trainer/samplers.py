@@ -273,8 +273,12 @@ class FastSamplerIter(Iterator[PreparedBatch]):
     """One epoch: owns the native Session (``.session``) and yields its batches in index order."""
     session: fast_sampler.Session
 
-    def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig):
+    def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig, table_features: bool = False):
         self.session = fast_sampler.Session(num_threads, max_items_in_queue, cfg.to_fast_sampler())
+        if table_features:
+            # opt-in: PreparedBatch.x is fast_sampler.TableRows(resident table, n_id) and the delivery skips the feature
+            # gather; models.SAGE aggregates its first layer straight from the table, anything else calls .materialize()
+            self.session.table_features = True
         # this façade's records have fields for the assembled features and the MFG ids: the native
         # exchange need not also export the ownership buckets a reference-shaped record would read
         self.session.compact_native_records = True
@@ -315,9 +319,11 @@ class FastSampler(ABCNeighborSampler):
     num_threads: int
     max_items_in_queue: int
     cfg: FastSamplerConfig
+    # not in the reference (samplers.py:381-399 has the three fields above): see FastSamplerIter
+    table_features: bool = False
 
     def __iter__(self):
-        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg)
+        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg, self.table_features)
 
     def __len__(self):
         return self.cfg.get_num_batches()

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as nat
+from .fast_sampler import TableRows
 
 
 def _p(t):
@@ -203,7 +204,11 @@ class SAGE(torch.nn.Module):
                 rowptr, col, _ = adj_t.csr()
                 hops.append((rowptr, col, int(size[1])))
             weights = [w for conv in self.convs for w in (conv.lin_l.weight, conv.lin_r.weight)]
+            if isinstance(x, TableRows):                 # fused first layer: the batch's rows are read from the table
+                x = (x.table, x.n_id)
             return _SageStack.apply(x, hops, self.training, 0.5, *weights)
+        if isinstance(x, TableRows):
+            x = x.materialize()
         for i, (adj_t, _e_id, size) in enumerate(adjs):
             x_target = x[:size[1]]
             x = self.convs[i]((x, x_target), adj_t)
@@ -257,6 +262,8 @@ class _SageStack(torch.autograd.Function):
 
     @staticmethod
     def usable(model, x, adjs):
+        if isinstance(x, TableRows):                     # (resident table, n_id): the first layer reads the table itself
+            x = x.table
         if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.float16, torch.float32) or x.requires_grad:
             return False
         k = x.size(1)
@@ -272,12 +279,19 @@ class _SageStack(torch.autograd.Function):
         nat.require_device()
         n_layers = len(hops)
         st = _stream()
+        n_id = None
+        if isinstance(x, tuple):                         # (table, n_id) of a TableRows: batch row j = table[n_id[j]]
+            x, n_id = x
         h = x
         operands, acts, wcats, seeds = [], [], [], []
         for i, (rowptr, col, T) in enumerate(hops):
             K = h.size(1)
             A = torch.empty((T, 2 * K), dtype=torch.float32, device=x.device)
-            if i == 0:
+            if i == 0 and n_id is not None:
+                nat.check(L.spp_sage_operand_forward_table(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
+                                                           h.stride(0) if h.size(0) > 1 else K, h.size(0), _p(n_id), K,
+                                                           _p(A), 2 * K, st))
+            elif i == 0:
                 nat.check(L.spp_sage_operand_forward(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
                                                      h.stride(0) if h.size(0) > 1 else K, K, _p(A), 2 * K, st))
             else:
@@ -301,7 +315,7 @@ class _SageStack(torch.autograd.Function):
         ctx.save_for_backward(*operands, *acts, *wcats, out, *hop_t)
         ctx.hop_T = [int(T) for (_r, _c, T) in hops]
         ctx.act = (float(p), int(bool(training)), seeds)
-        ctx.src_rows = [x.size(0)] + [a.size(0) for a in acts]
+        ctx.src_rows = [x.size(0) if n_id is None else n_id.numel()] + [a.size(0) for a in acts]
         return out
 
     @staticmethod
@@ -512,6 +526,8 @@ class GAT(torch.nn.Module):
             conv.apply(init_weights)
 
     def forward(self, x, adjs):
+        if isinstance(x, TableRows):                     # (the fused first layer exists for SAGE)
+            x = x.materialize()
         # the reference converts the features to fp32 first (models.py:221); GATConv here reads the fp16
         # rows directly (exact: every fp16 value is an fp32 value)
         for i, (adj_t, _e_id, size) in enumerate(adjs):

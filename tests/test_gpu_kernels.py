@@ -87,6 +87,38 @@ def test_gather_rows_strided_source(lib, row_bytes, stride):
                                        None) != 0
 
 
+@pytest.mark.parametrize("row_bytes,stride", [(200, 256), (200, 208), (8, 16), (24, 32), (408, 512), (504, 512), (88, 128)])
+@pytest.mark.parametrize("n_idx", [1, 2, 63, 64, 65, 255, 1023, 4097, 70001])
+def test_gather_rows_span_form(lib, row_bytes, stride, n_idx):
+    """Rows of 16k + 8 bytes out of a 16-byte-strided table take the span form of the row gather (16-byte loads, pieces
+    regrouped across lanes, aligned 16-byte stores: gather_body.cuh kVecSpan) -- the same bytes as the 8-byte form, on whole
+    and partial last iterations, and nothing outside the destination rows.  serial_index, fast_sampler.cpp:238-259."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(row_bytes * 131 + n_idx)
+    n_src = 3000
+    table = np.full((n_src, stride), 0xEE, dtype=np.uint8)
+    table[:, :row_bytes] = rng.integers(0, 256, size=(n_src, row_bytes), dtype=np.uint8)
+    idx = rng.integers(0, n_src, size=n_idx).astype(np.int32)
+    idx[-1] = n_src - 1                       # the table's last row: its padding is the last thing the allocation holds
+    want = orc.serial_index(np.ascontiguousarray(table[:, :row_bytes]), idx.astype(np.int64))
+    d_src, d_idx = dev(table), dev(idx)
+    assert d_src.data_ptr() % 16 == 0
+    outs = []
+    for span in (1, 0):
+        prev = lib.spp_tune(b"gather_span", span)
+        try:
+            raw = torch.full((n_idx * row_bytes + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+            check(lib, lib.spp_gather_rows_strided(P(d_src), n_src, row_bytes, stride, P(d_idx), 4, n_idx, n_idx, P(raw), None))
+            torch.cuda.synchronize()
+        finally:
+            lib.spp_tune(b"gather_span", prev)
+        got = raw.cpu().numpy()
+        np.testing.assert_array_equal(got[:n_idx * row_bytes].reshape(n_idx, row_bytes), want)
+        assert (got[n_idx * row_bytes:] == 0xAB).all()
+        outs.append(got)
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_to_row_major(lib):
     from oracle import oracle as orc
     rng = np.random.default_rng(0)

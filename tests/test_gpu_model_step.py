@@ -99,6 +99,94 @@ def test_sage_matches_plain_torch_on_a_sampled_batch():
         torch.testing.assert_close(hip.convs[i].lin_r.weight.grad, ref.lin_r[i].weight.grad, rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["member", "group", "batch"])
+@pytest.mark.parametrize("F", [128, 100])
+def test_fused_first_layer_from_the_resident_table(mode, F, monkeypatch):
+    """Row g1 (transferers.py:890-970 + driver/models.py:41-50): with ``table_features`` the Session delivers MFG + labels +
+    n_id and NO feature rows; PreparedBatch.x is TableRows(resident table, n_id) and models.SAGE aggregates its first layer
+    straight from the table.  Same seeds, same batches as the default Session: n_id names exactly the rows the default x
+    holds, the fused model's output is BIT-equal to the materialised path's (same summation order), the weight gradients
+    agree, both agree with plain torch, and anything that is not models.SAGE still gets a feature matrix (materialize())."""
+    import bench
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler, FastSamplerConfig
+    from salient_plusplus_amd.fast_trainer.transferers import DevicePrefetcher
+    from salient_plusplus_amd.models import GAT, SAGE
+    monkeypatch.setenv("SPP_GROUP_DELIVERY", "1" if mode == "group" else "0")
+    monkeypatch.setenv("SPP_GROUP_FETCH", "0" if mode == "batch" else "1")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "graph_a.npz"))
+    T_ = torch.from_numpy
+    rng = np.random.default_rng(F)
+    n = g["rowptr"].shape[0] - 1
+    x_host = T_((rng.standard_normal((n, F)) * 4).astype(np.float16))
+    cfg = FastSamplerConfig(
+        x_cpu=x_host, x_gpu=torch.empty(0), y=T_(g["y"]).unsqueeze(-1), rowptr=T_(g["rowptr"]), col=T_(g["col"]),
+        idx=T_(g["idx"]), batch_size=64, sizes=[15, 10, 5], skip_nonfull_batch=False, pin_memory=False,
+        distributed=False, partition_book=None, cache=fs.Cache(), force_exact_num_batches=False, exact_num_batches=0,
+        count_remote_frequency=False, use_cache=False)
+    dev = torch.device("cuda", 0)
+    plain = [b for (b,) in DevicePrefetcher([dev], iter(FastSampler(2, 4, cfg)))]
+    fused = [b for (b,) in DevicePrefetcher([dev], iter(FastSampler(2, 4, cfg, table_features=True)))]
+    torch.cuda.synchronize()
+    assert len(plain) == len(fused) > 1
+    C = int(g["y"].max()) + 1
+    torch.manual_seed(0)
+    hip = SAGE(F, 64, C, 3).to(dev).train()
+    ref = bench.TorchSAGE(F, 64, C, 3).to(dev).eval()
+    for i in range(3):
+        ref.lin_l[i].weight.data.copy_(hip.convs[i].lin_l.weight.data)
+        ref.lin_r[i].weight.data.copy_(hip.convs[i].lin_r.weight.data)
+    for bp, bf in zip(plain, fused):
+        assert isinstance(bf.x, fs.TableRows) and bf.x.shape == bp.x.shape and bf.x.dtype == bp.x.dtype
+        assert bf.idx_range == bp.idx_range and torch.equal(bf.y, bp.y)
+        assert torch.equal(bf.x.materialize(), bp.x)                  # the same rows, by the HIP row gather
+        assert torch.equal(x_host.to(dev)[bf.x.n_id], bp.x)           # ... and they are x[n_id]
+        for hp, hf in zip(bp.adjs, bf.adjs):
+            for a, b in zip(hp.adj_t.csr()[:2], hf.adj_t.csr()[:2]):
+                assert torch.equal(a, b)
+        outs, grads = [], []
+        for b in (bp, bf):
+            hip.zero_grad()
+            torch.manual_seed(1234)                                   # the dropout seeds come from torch's CPU generator
+            out = hip(b.x, b.adjs)
+            torch.nn.functional.nll_loss(out, b.y.reshape(-1)).backward()
+            outs.append(out.detach().clone())
+            grads.append([p.grad.detach().clone() for p in hip.parameters()])
+        assert torch.equal(outs[0], outs[1])                          # forward: the same sums in the same order
+        for ga, gb in zip(*grads):                                    # backward: the small hops' input gradients are fp32
+            torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-6)  # atomics (order not fixed) in BOTH paths
+        hip.eval()
+        with torch.no_grad():
+            torch.testing.assert_close(hip(bf.x, bf.adjs), ref(bp.x, bp.adjs), rtol=1e-4, atol=1e-5)
+        hip.train()
+    # a consumer without the fused layer: GAT materialises the rows itself
+    gat = GAT(F, 32, C, 3).to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(gat(fused[0].x, fused[0].adjs), gat(plain[0].x, plain[0].adjs))
+
+
+def test_table_features_refused_for_partitioned_sessions():
+    from salient_plusplus_amd import fast_sampler as fs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "graph_a.npz"))
+    T_ = torch.from_numpy
+    n = g["rowptr"].shape[0] - 1
+    c = fs.Config()
+    c.x_cpu, c.x_gpu, c.y = torch.empty((0, g["x"].shape[1]), dtype=torch.float16), T_(g["x"]), T_(g["y"]).unsqueeze(-1)
+    c.rowptr, c.col, c.idx = T_(g["rowptr"]), T_(g["col"]), T_(g["idx"])
+    c.batch_size, c.sizes = 64, [5, 5]
+    c.skip_nonfull_batch = c.pin_memory = c.force_exact_num_batches = False
+    c.exact_num_batches = 0
+    c.distributed = True
+    c.partition_book = fs.RangePartitionBook(0, 1, torch.tensor([0, n]))
+    c.cache = fs.Cache()
+    c.count_remote_frequency = c.use_cache = False
+    s = fs.Session(2, 4, c)
+    s.table_features = True
+    with pytest.raises(RuntimeError, match="table_features"):
+        s.blocking_get_batch_distributed()
+    s.close()
+
+
 def test_end_to_end_training_learns_through_the_data_path():
     """The reference's only integration check is 'training reaches accuracy' (SURVEY §4).  A small
     graph whose labels depend on a node's own features AND on the mean of its neighbours' is
