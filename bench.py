@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-fused-leg", action="store_true",
                     help="N=1, SAGE: skip the model-step leg of the opt-in fused consumer (Session(table_features) + "
                          "models.SAGE reading its first layer straight from the resident feature table)")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="confine the process to this many cores before torch is imported (0 = no confinement): the host "
+                         "budget of one rank of an 8-rank node (16-core quota / 8 = 2) rehearsed on one GPU; not under rocprofv3")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="launcher only: print the GPU count found without the HIP runtime and whether libamdhip64 is mapped "
                          "into the launcher process, start nothing")
@@ -217,6 +220,24 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
     _a = parse()
     if _a.gpus > 1 or _a.launch_dry_run:
         raise SystemExit(launch_ranks(_a))
+
+
+
+def confine_to_cores(n: int) -> list:
+    """--cpu-cores N: the host budget of one rank on an 8-rank node, rehearsed on one GPU.  The process (and every thread
+    it starts later: torch's, the Session's launcher / exchanger, RCCL's proxies) is confined to the first N cores of its
+    affinity mask.  Runs before `import torch`: nothing has touched the GPU yet.  The reference budgets this explicitly
+    (utils/exp_driver.py:48-49 num_workers per trainer, driver/parser.py:87-88)."""
+    cores = sorted(os.sched_getaffinity(0))[:max(1, n)]
+    os.sched_setaffinity(0, cores)
+    return cores
+
+
+if __name__ == "__main__":
+    _cores = [v for k, v in zip(sys.argv, sys.argv[1:]) if k == "--cpu-cores"] + \
+             [k.split("=", 1)[1] for k in sys.argv if k.startswith("--cpu-cores=")]
+    if _cores and int(_cores[-1]) > 0:
+        confine_to_cores(int(_cores[-1]))
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -690,8 +711,10 @@ def main():
     win = []                                      # (seconds, edges, nodes) per window
     prof_cum = []                                 # cumulative (ms, launches) of the timed delivery launches after each window
     chain_alg_bytes = 0                           # the sampler's algorithmic bytes over the timed region (this rank)
+    groups_per_window = []                        # sampling groups opened in each window (a window that opens two carries two chains' work)
     for _w in range(R):
         edges = nodes = 0
+        g0 = fs.groups_opened()
         t0 = time.perf_counter()
         step_t = [] if os.environ.get("SPP_BENCH_STEP_TIMES") == "1" else None
         for _ in range(a.steps):
@@ -730,6 +753,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         win.append((time.perf_counter() - t0, float(edges), float(nodes)))
+        groups_per_window.append(fs.groups_opened() - g0)
         # (outside the window's clock) the delivery launches timed so far: per-window in-situ duration of the dominant kernel,
         # which tells a slow window of the GPU (longer launches) from one of the host or the queue (same launches, more gaps)
         _ms, _n, _u = C.c_double(0), C.c_int64(0), C.c_int64(0)
@@ -933,10 +957,16 @@ def main():
                         "ms_per_step_trimmed_mean": dt_trimmed / a.steps * 1e3,   # without the slowest and the fastest of >= 8 windows
                         "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
                         "ms_per_step_all": [round(v, 5) for v in window_ms],
+                        # sampling groups (one chain of up to 16 batches each) rank 0 opened in each window, and the windows
+                        # that opened two or more: K steps are K / 16 groups, so with K = 20 one window in four carries two
+                        # chains' work (a structural long window, not a stall)
+                        "groups_opened_all": groups_per_window,
+                        "opens_two_groups": [k for k, n_ in enumerate(groups_per_window) if n_ >= 2],
                         # in-situ duration of the timed delivery launches of each window (rank 0; live HIP events)
                         "deliver_us_all": [round(1e3 * (b[0] - a_[0]) / max(1, b[1] - a_[1]), 1)
                                            for a_, b in zip([(0.0, 0)] + prof_cum[:-1], prof_cum)]},
             "timed_region_s": timed_total_s,          # all R windows (also under "windows")
+            "host": {"cpu_cores_flag": a.cpu_cores, "affinity_cores": len(os.sched_getaffinity(0)), "cpu_share": host_cpu_share()},
             "hbm": {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
                     "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
                     "torch_alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),

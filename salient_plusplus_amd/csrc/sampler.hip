@@ -1839,6 +1839,27 @@ static hipError_t create_data_stream(hipStream_t* st, bool sampling) {
   static const int prio_s = getenv("SPP_SAMPLING_PRIORITY") ? parse("SPP_SAMPLING_PRIORITY") : prio_all;
   static const int prio_d = getenv("SPP_DELIVERY_PRIORITY") ? parse("SPP_DELIVERY_PRIORITY") : prio_all;
   const int prio = sampling ? prio_s : prio_d;
+  // Measurement aid (profiles/r05_ab_INDEX.md): SPP_DELIVERY_CU_MASK=n / SPP_SAMPLING_CU_MASK=n confine the delivery (and
+  // exchange) stream / the sampling streams to n compute units.  SPP_CU_MASK_LAYOUT=interleaved (default): the first n bits
+  // (the driver deals a multi-XCD part's mask bits round-robin over the XCDs); =blocked: the first n / 8 bits of every
+  // 32-bit word.  Unset = the whole chip.
+  static const int mask_d = getenv("SPP_DELIVERY_CU_MASK") ? atoi(getenv("SPP_DELIVERY_CU_MASK")) : 0;
+  static const int mask_s = getenv("SPP_SAMPLING_CU_MASK") ? atoi(getenv("SPP_SAMPLING_CU_MASK")) : 0;
+  const int ncu = sampling ? mask_s : mask_d;
+  if (ncu > 0 && ncu < 256) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const char* lay = getenv("SPP_CU_MASK_LAYOUT");
+    if (lay && !strcmp(lay, "blocked")) {
+      const int per_xcd = (ncu + 7) / 8;
+      int left = ncu;
+      for (int x = 0; x < 8 && left > 0; ++x)
+        for (int k = 0; k < per_xcd && k < 32 && left > 0; ++k, --left) mask[x] |= 1u << k;
+    } else {
+      for (int k = 0; k < ncu; ++k) mask[k >> 5] |= 1u << (k & 31);
+    }
+    if (hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+  }
   return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 

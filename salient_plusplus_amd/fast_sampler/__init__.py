@@ -146,6 +146,12 @@ def _stride_bytes(t: Optional[torch.Tensor]) -> int:
 
 
 _resident = _ResidentCache()
+_groups_opened = 0          # sampling groups fetched by all Sessions of this process (measurement aid: groups_opened())
+
+
+def groups_opened() -> int:
+    """Sampling groups (up to 16 batches: one chain, one exchange) the Sessions of this process have fetched so far."""
+    return _groups_opened
 
 
 _graph_epoch = 0
@@ -938,6 +944,8 @@ class Session:
                 self._finish()
             return None
         n = n_c.value
+        global _groups_opened
+        _groups_opened += 1
         dev = self._dev
         cfg = self.config
         distributed = self._distributed
@@ -1270,17 +1278,26 @@ class Session:
 
     # ---- remote frequency counting (simulation cache strategy) ----
     def _count_remote(self, partition_nids, rank):
-        n = self._rowptr.numel() - 1
-        if self._freq is None:
-            self._freq = torch.zeros(n, dtype=torch.int64, device=self._dev)
-        for m, t in enumerate(partition_nids):
-            if m != rank and t.numel():
-                self._freq.index_add_(0, t, torch.ones_like(t))
+        # The ids were written by the delivery launch that was just enqueued: the counting runs on THAT stream.  (A consumer
+        # that named its delivery stream once -- DevicePrefetcher / DeviceDistributedPrefetcher in direct mode -- calls
+        # without a stream context; on its current stream the index_add_ would read ids no launch has written yet.)
+        st = self.export_stream if self.export_stream is not None else torch.cuda.current_stream(self._dev)
+        with torch.cuda.stream(st):
+            n = self._rowptr.numel() - 1
+            if self._freq is None:
+                self._freq = torch.zeros(n, dtype=torch.int64, device=self._dev)
+            for m, t in enumerate(partition_nids):
+                if m != rank and t.numel():
+                    self._freq.index_add_(0, t, torch.ones_like(t))
+        self._freq_stream = st
 
     def reduce_multithreaded_frequency_counts(self):
         if self._freq_reduced:
             return
         if self._freq is not None:
+            fst = getattr(self, "_freq_stream", None)
+            if fst is not None:                        # the counts were accumulated on the delivery stream
+                torch.cuda.current_stream(self._dev).wait_stream(fst)
             nz = self._freq.nonzero().view(-1)
             f = self._freq[nz]
             order = torch.argsort(f, descending=True, stable=True)

@@ -45,6 +45,9 @@ def _check_common(d, n_gpus):
     assert abs(d["ms_per_step"] - sum(allw) / len(allw)) <= 1e-4 * d["ms_per_step"] + 1e-5
     assert "ms_per_step_trimmed_mean" in w and "ms_per_step_median" in w
     assert len(w["deliver_us_all"]) == w["n"] and all(v >= 0 for v in w["deliver_us_all"])   # per-window in-situ delivery time
+    # which windows carry two chains' work: 24 steps = 1.5 groups of 16, so every window opens 1 or 2 groups
+    assert len(w["groups_opened_all"]) == w["n"] and sum(w["groups_opened_all"]) >= 1
+    assert w["opens_two_groups"] == [k for k, n_ in enumerate(w["groups_opened_all"]) if n_ >= 2]
     assert abs(d["value"] - d["sampled_edges_per_batch"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -69,6 +72,11 @@ def test_single_gpu_line():
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     m = d["model_step"]
     assert m["ms_per_step_with_data_path"] > 0 and d["epoch_time_s_with_model_step"] > 0
+    # row g1: both consumers in the line under distinct keys -- the default (x delivered) and the fused first layer
+    f = m["fused_first_layer"]
+    assert f["ms_per_step_with_data_path"] > 0 and f["ms_per_step_model_only_resident_batch"] > 0
+    assert abs(f["data_path_cost_ms"] - (f["ms_per_step_with_data_path"] - f["ms_per_step_model_only_resident_batch"])) < 1e-9
+    assert abs(m["data_path_cost_ms"] - (m["ms_per_step_with_data_path"] - m["ms_per_step_model_only_resident_batch"])) < 1e-9
 
 
 def test_partitioned_path_line_with_the_ddp_leg():

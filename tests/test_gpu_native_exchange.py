@@ -137,6 +137,75 @@ def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots, issue, mo
     assert all(stats[r] > 0 for r in range(P))     # counts / ids / rows really travelled
 
 
+def _run_rank_counting(rank, P, comms, g, offsets, nb, bs, errors, out):
+    it = None
+    try:
+        import dataclasses
+        from oracle import oracle as orc
+        from salient_plusplus_amd import fast_sampler as fs
+        from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+        from salient_plusplus_amd.fast_trainer.transferers import DeviceDistributedPrefetcher
+        torch.cuda.set_device(0)
+        fs.set_native_comm(comms[rank])
+        cfg, idx = _rank_cfg(g, rank, P, offsets, False, nb, bs, fs)
+        cfg = dataclasses.replace(cfg, count_remote_frequency=True)
+        ranges = orc.batch_ranges(len(idx), bs, False, True, nb)
+        dev = torch.device("cuda", 0)
+        it = iter(FastSampler(2, 8, cfg))
+        assert it.session.native_exchange
+        pre = DeviceDistributedPrefetcher([dev], it, True)
+        # a backlog on the delivery stream: the counting must follow the delivery launches on it, not race them on the
+        # consumer's stream
+        with torch.cuda.stream(pre.side.stream):
+            torch.cuda._sleep(200_000_000)
+        got = sum(1 for _ in pre)
+        assert got == nb
+        lo, hi = int(offsets[rank]), int(offsets[rank + 1])
+        want = {}
+        for k in range(nb):
+            m = orc.sample_batch(g["rowptr"], g["col"], idx, int(ranges[k][0]), int(ranges[k][1]), SIZES)
+            for v in m.n_id[(m.n_id < lo) | (m.n_id >= hi)]:
+                want[int(v)] = want.get(int(v), 0) + 1
+        st = it.get_distributed_stats()
+        f, v = st.remote_frequency_tensor.numpy(), st.remote_vertices_ordered_by_freq.numpy()
+        assert f.shape[0] == len(want) and (np.diff(f) <= 0).all()
+        assert all(want[int(vv)] == int(ff) for vv, ff in zip(v, f))
+        out[rank] = len(want)
+        it.session.close()
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        errors.append(f"rank {rank}: {e}\n{traceback.format_exc()}")
+        if it is not None:
+            it.session.close()
+        comms[rank].close()
+    finally:
+        from salient_plusplus_amd import fast_sampler as fs
+        fs.set_native_comm(None)
+
+
+def test_remote_frequency_counting_through_the_native_prefetcher():
+    """count_remote_frequency (fast_sampler.cpp:1093-1103, :835-880) with the native exchange behind
+    DeviceDistributedPrefetcher: the prefetcher requests batches without a stream context (the Session was told the
+    delivery stream once), so the counting has to order itself behind the delivery launch that writes the ids."""
+    from salient_plusplus_amd import fast_sampler as fs
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    P, offsets = 2, [0, 1400, n]
+    comms = fs.NativeComm.local(P)
+    errors, out = [], {}
+    ts = [threading.Thread(target=_run_rank_counting, args=(r, P, comms, g, offsets, 5, 24, errors, out)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    hung = [t for t in ts if t.is_alive()]
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not hung, "rank thread hung"
+    assert all(out[r] > 0 for r in range(P))
+
+
 @pytest.mark.parametrize("P,use_cache,nb,bs,slots", [(2, True, 7, 16, 4), (3, True, 5, 24, 16), (8, True, 9, 8, 32),
                                                      (2, True, 37, 4, 32)])
 @pytest.mark.parametrize("issue", ["thread", "consumer"])
