@@ -921,7 +921,8 @@ def main():
                               "streams beside the delivery kernel, so spans overlap (the per-batch cost in the step is smaller than the span)"}
             pmc_txt = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_partitioned_pmc_traffic_per_kernel.txt" if distributed
                                                     else "r0?_pipeline_pmc_traffic_per_kernel.txt")))
-            if pmc_txt:
+            # (the committed passes are of S-papers with its own fan-outs: any other workload keeps "traffic": null)
+            if pmc_txt and a.workload == "S-papers" and not a.fanouts:
                 mb = 0.0
                 for ln in open(pmc_txt[-1]):
                     f_ = ln.split()

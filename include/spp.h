@@ -331,7 +331,15 @@ int64_t spp_session_num_consumed_batches(const spp_session* s);
 /* fills ranges (2*num_total_batches int32) -- the table of fast_sampler.cpp:587-627 */
 spp_status spp_session_batch_ranges(const spp_session* s, int32_t* out_start_stop);
 /* BLOCKING. Returns 1 and fills *out when the next batch (index order) is ready,
- * 0 at end of epoch (the reference returns None), <0 on error. */
+ * 0 at end of epoch (the reference returns None), <0 on error.
+ * How far ahead the session samples (the counterpart of max_items_in_queue, fast_sampler.cpp:533-586): the slots form
+ * `sets` slot-sets of group_size batches; the launcher keeps chains in flight for at most
+ *     sets - refill_lag   groups beyond the groups the consumer has FINISHED
+ * (refill_lag = SPP_REFILL_LAG, default 1, applied only with >= 3 sets and capped at sets - 2: the chain that refills a
+ * freed set is enqueued one group later, for a set whose deliveries completed a group ago).  A group counts as finished
+ * when the consumer COMES BACK FOR MORE after exporting its last batch -- at the next spp_session_next /
+ * spp_session_try_next / spp_session_next_group -- not at that export: a consumer that exports a group's last batch and then
+ * only polls slot events, or calls spp_session_quiesce, gets no refill until it asks for the next batch. */
 int spp_session_next(spp_session* s, spp_batch_desc* out);
 /* Non-blocking form (try_get_batch, fast_sampler.cpp:658-670): 2 when the next batch is not ready
  * yet, otherwise exactly what spp_session_next returns. */
@@ -435,7 +443,9 @@ typedef struct spp_exchange_cfg {
  * consumption (sampling chains and exchanges of the slot-sets in flight) and that work has completed
  * on the GPU.  Call it on every rank before issuing collectives of ANOTHER communicator (e.g. a
  * torch.distributed barrier): kernels of two communicators that wait for their peers must not be
- * queued behind one another in opposite orders on different ranks. */
+ * queued behind one another in opposite orders on different ranks.  A finished group that has not been reported yet
+ * (see spp_session_next: the report is deferred to the consumer's next request) stays unreported: quiesce starts no
+ * refill chain of its own. */
 spp_status spp_session_quiesce(spp_session* s);
 /* bytes this rank sent / received through the exchange so far (ids + rows + counts) */
 spp_status spp_session_exchange_stats(const spp_session* s, int64_t* sent_bytes, int64_t* recv_bytes);

@@ -72,7 +72,7 @@ constexpr int kNT = 256;         // workgroup size of the per-target / per-edge 
 constexpr int kFastMaxFanout = 32;
 constexpr int kScanNT = 1024;
 
-enum : int32_t { kErrEdgeCap = 1, kErrNodeCap = 2, kErrDrawCap = 4, kErrBucketCap = 8, kErrHandoff = 16 };
+enum : int32_t { kErrEdgeCap = 1, kErrNodeCap = 2, kErrDrawCap = 4, kErrBucketCap = 8 };
 
 // Geometry of the radix-partitioned dedup (fixed per sampler).
 struct DedupGeom {
@@ -192,10 +192,6 @@ struct SlotPtrs {
   int32_t* bsum0;
   int32_t* bsum1;
   int32_t* ctr;        // "last workgroup" ticket counter (zero between launches)
-  // k_hop_finish (round 5): per hop and 1024-position tile one 8-byte status granule {tag, value} (zeroed per chain with
-  // the counters above: they share the memset), and the first target row of every tile (written by k_hop_pick)
-  unsigned long long* tstat;
-  int32_t* tfirst;
   SlotState* st;
   int32_t* out_rowptr[SPP_MAX_HOPS];  // processing order
   int32_t* out_col[SPP_MAX_HOPS];
@@ -619,9 +615,7 @@ struct FuseArgs {
   uint32_t idmask;
   int32_t lds_off;   // first int of the staging area inside the dynamic LDS block (behind the picks' columns)
   int32_t tile_cap;  // edges a workgroup can hold: kNT * max(1, f)
-  int32_t tfirst_off;  // this hop's first entry in the slot's tfirst array (k_hop_finish); < 0: not wanted
 };
-constexpr int kFinTileLog2 = 10;
 
 template <bool kGeneric, typename ColT, bool kStub, bool kHdr = false, bool kFuse = false>
 __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ slots, GroupGrid gg,
@@ -736,13 +730,6 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   bool live = i < T;
   if (live && self_prefix && (p0 + cnt > ecap || (smp && dbase + (int64_t)f * (r0 + 1) > dcap))) live = false;
   if (live) out_rp[i] = p0;
-  if (!kGeneric && live && cnt > 0 && fa.tfirst_off >= 0) {
-    // k_hop_finish works in tiles of kFinTile edge positions and owns the rows that START in its tile: the row that
-    // reaches a tile's first position from below names the next row as that tile's first (lower_bound of the row
-    // offsets at the tile boundary, without a search)
-    const int32_t jt = (p0 + cnt) >> kFinTileLog2;
-    if ((jt << kFinTileLog2) > p0) G(s.tfirst)[fa.tfirst_off + jt] = i + 1;
-  }
   if (err0) live = false;  // an earlier kernel of the chain failed: nothing to do
   if (!live) {
     cnt = 0;
@@ -1479,305 +1466,6 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
   }
 }
 
-// ----------------------------------------------------------------------------------------------
-// k_hop_flag + k_hop_rows as ONE pass (round 5)
-// ----------------------------------------------------------------------------------------------
-// The local id of a node that is new in this hop is the number of first occurrences at EARLIER edge positions of the
-// whole hop, which is why the two kernels were two: every workgroup's bitmap counts had to be in before any row could
-// be written.  Here a workgroup owns a tile of kFinTile edge positions and the rows that START in it, and gets the count
-// of the tiles before it by a decoupled look-back over 8-byte {tag, value} status granules (one per tile, zeroed by the
-// chain's memset; agent-scope atomic stores and loads on both sides: cdna_hip_programming.md Guideline 16, form R2):
-// tile j publishes its own count (tag A), sums its predecessors' back to the nearest inclusive prefix (tag P) and
-// publishes its own inclusive prefix.  Workgroups are dispatched in index order, so a predecessor is running or done;
-// every wait is bounded (kErrHandoff on expiry: no hang, the batch is reported failed).
-// What goes away: the evals array (4 B per edge written and read back), the rank-record lookups of every new node's
-// edge (a 16-byte random read each: now two LDS reads; only an edge that repeats a node first met in an EARLIER tile
-// still reads that tile's record -- through the same atomics) and a launch per hop.
-// The rank records and block prefixes are still written (plain stores) for the next hop's k_bucket_dedup.
-constexpr int kFinRounds = 4;
-constexpr int kFinTile = kNT * kFinRounds;           // 1024 positions = 4 rank blocks = 16 bitmap words
-static_assert(kFinTile == (1 << kFinTileLog2), "k_hop_pick names the tiles' first rows");
-constexpr int kFinWords = kFinTile / 64;
-constexpr int kFinOver = 32;                         // a row that starts in the tile ends < 32 positions past it (fanout <= 32)
-constexpr uint32_t kTileAggregate = 1u, kTilePrefix = 2u;
-constexpr uint32_t kSpinLimit = 1u << 21;
-
-typedef SPP_GLOBAL unsigned long long gu64;
-__device__ __forceinline__ unsigned long long ld_agent(const gu64* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(gu64* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the inclusive prefix tile k has published (k < 0: nothing before the first tile); false: gave up waiting
-__device__ __forceinline__ bool wait_tile_prefix(const gu64* tstat, int32_t k, uint32_t& out) {
-  out = 0u;
-  if (k < 0) return true;
-  for (uint32_t spins = 0; spins < kSpinLimit; ++spins) {
-    const unsigned long long w = ld_agent(tstat + k);
-    if ((uint32_t)(w >> 32) == kTilePrefix) {
-      out = (uint32_t)w;
-      return true;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return false;
-}
-
-__global__ __launch_bounds__(kNT) void k_hop_finish(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h, int32_t f,
-                                                     uint32_t idmask, int32_t idbits, int32_t ucap, int64_t pcap,
-                                                     int32_t toff) {
-  SPP_GROUP_BLOCK(gg);
-  extern __shared__ int32_t fin_lds[];  // [f][kNT]: a row's local ids, one column per lane
-  int32_t (*a)[kNT] = reinterpret_cast<int32_t (*)[kNT]>(fin_lds);
-  __shared__ uint32_t vals[kFinTile + kFinOver];          // table value of every position of the tile (+ the overhang)
-  __shared__ unsigned long long wbits[kFinWords + 1];     // first-occurrence bitmap; [kFinWords]: the overhang's 32 positions
-  __shared__ int32_t wpre[kFinWords + 1];                 // set bits of the tile before each word; [kFinWords]: the tile's count
-  __shared__ uint32_t x_sh;                               // first occurrences in the tiles before this one
-  __shared__ int32_t ok_sh;
-  const SlotPtrs& s = slots[gg.first_slot + by_];
-  SPP_GLOBAL SlotState* st = G(s.st);
-  const SPP_GLOBAL uint32_t* inv = G(s.inv);
-  const SPP_GLOBAL uint32_t* res = G(s.res);
-  const SPP_GLOBAL int32_t* cval = G(s.cval);
-  const SPP_GLOBAL int32_t* rp = G(s.out_rowptr[h]);
-  const SPP_GLOBAL int32_t* tfirst = G(s.tfirst) + toff;
-  gu64* tstat = G(s.tstat) + toff;
-  gu64* fw64 = reinterpret_cast<gu64*>(G(s.fwords));      // a rank record = two 8-byte granules {bits}, {pre | pad << 32}
-  SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
-  SPP_GLOBAL uint8_t* dtag = G(s.dtag);
-  const int tid = threadIdx.x, wid = tid / kWave, lane = tid & (kWave - 1);
-  const int32_t j = (int32_t)bx_;
-  const int64_t base = (int64_t)j * kFinTile;
-  // ---- round trip 1: state words, this tile's slice of inv (+ the overhang), the tile's row range
-  const int32_t err0 = st->error;
-  const int32_t E = st->E[h];
-  const uint32_t T = (uint32_t)st->cnt[h];
-  uint32_t slot[kFinRounds];
-#pragma unroll
-  for (int r = 0; r < kFinRounds; ++r) {
-    const int64_t p = base + r * kNT + tid;
-    slot[r] = inv[p < pcap ? p : pcap - 1];
-  }
-  const int64_t po = base + kFinTile + (tid & (kFinOver - 1));
-  const uint32_t oslot = inv[po < pcap ? po : pcap - 1];  // (every wave loads the overhang's 32 entries: no predicate)
-  const int32_t i_lo = j == 0 ? 0 : tfirst[j];
-  const int32_t i_hi_raw = tfirst[j + 1];
-  if (err0) {
-    if (j == 0 && tid == 0) {  // keep the later hops' sizes defined
-      st->cnt[h + 1] = (int32_t)T;
-      st->dbase[h + 1] = st->dbase[h];
-    }
-    return;
-  }
-  const int32_t ntiles = E > 0 ? (E + kFinTile - 1) / kFinTile : 1;  // tile 0 always takes part
-  if (j >= ntiles) return;
-  // ---- round trip 2: the table values, through inv (positions past E read entry 0: no predicate on the load)
-  uint32_t val[kFinRounds];
-#pragma unroll
-  for (int r = 0; r < kFinRounds; ++r) {
-    const int64_t p = base + r * kNT + tid;
-    val[r] = res[p < E ? slot[r] : 0u];
-  }
-  const uint32_t oval = res[po < E ? oslot : 0u];
-  // (same round trip) the bounds of this lane's row of the first row iteration, then its first eight neighbour entries:
-  // neither depends on the look-back below, which they overlap
-  const int32_t i_hi = j == ntiles - 1 ? (int32_t)T : i_hi_raw;
-  int32_t first_p0 = 0, first_n = 0;
-  int32_t first_c[8];
-  {
-    const int32_t i = i_lo + tid;
-    const bool have = i < i_hi;
-    const int32_t ic = have ? i : (i_hi > 0 ? i_hi - 1 : 0);
-    first_p0 = rp[ic];
-    const int32_t p1 = rp[ic + 1];
-    first_n = have ? p1 - first_p0 : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t p = (u < first_n) ? (int64_t)first_p0 + u : (int64_t)first_p0;
-      first_c[u] = cval[p < pcap ? p : pcap - 1];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < kFinRounds; ++r) {
-    const int64_t p = base + r * kNT + tid;
-    const bool flag = p < E && val[r] == T + (uint32_t)p;  // first occurrence of a node that is new in this hop
-    const unsigned long long bits = __ballot(flag);
-    vals[r * kNT + tid] = val[r];
-    if (lane == 0) wbits[r * (kNT / kWave) + wid] = bits;
-  }
-  if (wid == 0) {
-    const bool oflag = lane < kFinOver && po < E && oval == T + (uint32_t)po;
-    const unsigned long long ob = __ballot(oflag);
-    if (lane < kFinOver) vals[kFinTile + lane] = oval;
-    if (lane == 0) wbits[kFinWords] = ob;
-  }
-  __syncthreads();
-  // ---- wave 0: word prefixes, the rank records, the look-back
-  if (wid == 0) {
-    const int32_t mine = lane < kFinWords ? __popcll(wbits[lane]) : 0;
-    const int32_t inc = wave_inclusive_scan(mine);
-    const int32_t count = __shfl(inc, kFinWords - 1, kWave);  // first occurrences in this tile
-    if (lane < kFinWords) wpre[lane] = inc - mine;
-    if (lane == 0) wpre[kFinWords] = count;
-    // rank record of word `lane`: {bits}, {set bits in the earlier words of its 256-position block | set bits in the
-    // earlier blocks of the tile << 32} -- atomic (write-through) stores: a later tile may read them in this launch
-    const int32_t blk_pre = __shfl(inc - mine, lane & ~3, kWave);  // the tile prefix at the block's first word
-    if (lane < kFinWords) {
-      const int64_t w = (int64_t)j * kFinWords + lane;
-      st_agent(fw64 + 2 * w, wbits[lane]);
-      st_agent(fw64 + 2 * w + 1, (unsigned long long)(uint32_t)(inc - mine - blk_pre) | ((unsigned long long)(uint32_t)blk_pre << 32));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records are out before the status word says so
-    uint32_t acc = 0u;
-    int ok = 1;
-    if (j == 0) {
-      if (lane == 0) st_agent(tstat, ((unsigned long long)kTilePrefix << 32) | (uint32_t)count);
-    } else {
-      if (lane == 0) st_agent(tstat + j, ((unsigned long long)kTileAggregate << 32) | (uint32_t)count);
-      int32_t kb = j - 1;
-      for (uint32_t spins = 0;;) {
-        const int32_t k = kb - lane;
-        // (before the first tile: a prefix of zero)
-        const unsigned long long w = k >= 0 ? ld_agent(tstat + k) : ((unsigned long long)kTilePrefix << 32);
-        const uint32_t tag = (uint32_t)(w >> 32);
-        const unsigned long long pfx = __ballot(tag == kTilePrefix);
-        const unsigned long long inval = __ballot(tag != kTilePrefix && tag != kTileAggregate);
-        const int first_p = pfx ? __ffsll((long long)pfx) - 1 : kWave - 1;  // nearest tile with an inclusive prefix (else: the whole window)
-        const unsigned long long need = first_p >= 63 ? ~0ull : ((1ull << (first_p + 1)) - 1ull);
-        if (inval & need) {  // a tile between here and there has published nothing yet
-          if (++spins > kSpinLimit) {
-            ok = 0;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        const uint32_t v = lane <= first_p ? (uint32_t)w : 0u;
-        const uint32_t sum = wave_inclusive_scan(v);
-        acc += __shfl(sum, kWave - 1, kWave);
-        if (pfx) break;
-        kb -= kWave;
-      }
-      if (lane == 0) st_agent(tstat + j, ((unsigned long long)kTilePrefix << 32) | (acc + (uint32_t)count));
-    }
-    const int32_t blk_ex = __shfl(inc - mine, (lane * 4) & (kWave - 1), kWave);  // (every lane takes part in the shuffle)
-    if (lane < kFinRounds)  // exclusive prefix of the tile's rank blocks, for the next hop's k_bucket_dedup
-      G(s.fsum)[(int64_t)j * kFinRounds + lane] = (int32_t)acc + blk_ex;
-    if (lane == 0) {
-      x_sh = acc;
-      ok_sh = ok;
-      if (!ok) atomicOr(&s.st->error, kErrHandoff);
-      if (j == ntiles - 1) {  // the hop's totals
-        const int32_t U = (int32_t)T + (int32_t)acc + count;
-        st->cnt[h + 1] = U;
-        st->dbase[h + 1] = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
-        if (U > ucap) atomicOr(&s.st->error, kErrNodeCap);
-      }
-    }
-  }
-  __syncthreads();
-  if (!ok_sh || E == 0) return;
-  const uint32_t X = x_sh;
-  // ---- the rows that start in this tile: one lane per row (k_hop_rows' work)
-  for (int32_t it = i_lo; it < i_hi; it += kNT) {
-    int32_t p0, n;
-    int32_t c[8];
-    if (it == i_lo) {  // (loaded before the look-back)
-      p0 = first_p0;
-      n = first_n;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) c[u] = first_c[u];
-    } else {
-      const int32_t i = it + tid;
-      const bool have = i < i_hi;
-      const int32_t ic = have ? i : i_hi - 1;
-      p0 = rp[ic];
-      const int32_t p1 = rp[ic + 1];
-      n = have ? p1 - p0 : 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t p = (u < n) ? (int64_t)p0 + u : (int64_t)p0;
-        c[u] = cval[p < pcap ? p : pcap - 1];
-      }
-    }
-    uint32_t farmask = 0u;
-    for (int32_t k0 = 0; k0 < n; k0 += 8) {
-      if (k0 > 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {  // the neighbour entries of the row (clamped: the loads issue back to back)
-          const int64_t p = (k0 + u < n) ? (int64_t)p0 + k0 + u : (int64_t)p0;
-          c[u] = cval[p < pcap ? p : pcap - 1];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (k0 + u >= n) break;
-        const uint32_t p = (uint32_t)(p0 + k0 + u);
-        const uint32_t v = vals[p - (uint32_t)base];
-        int32_t id = (int32_t)v;
-        if (v >= T) {
-          const uint32_t qq = v - T;  // the node's first position in this hop (<= p)
-          if (qq >= (uint32_t)base) {
-            const uint32_t lq = qq - (uint32_t)base;
-            const uint32_t w = lq < (uint32_t)kFinTile ? (lq >> 6) : (uint32_t)kFinWords;
-            const uint32_t bit = lq < (uint32_t)kFinTile ? (lq & 63u) : lq - (uint32_t)kFinTile;
-            id = (int32_t)(T + X) + wpre[w] + __popcll(wbits[w] & ((1ull << bit) - 1ull));
-            if (qq == p) {  // n_ids.push_back(c) at its first occurrence
-              n_ids[id] = (int32_t)((uint32_t)c[u] & idmask);
-              if (idbits < 32) dtag[id] = (uint8_t)((uint32_t)c[u] >> idbits);  // the node's degree tag travels with it
-            }
-          } else {
-            farmask |= 1u << (k0 + u);  // first met in an EARLIER tile: resolved below (the raw value stays in the column)
-          }
-        }
-        a[k0 + u][tid] = id;
-      }
-    }
-    // Edges that repeat a node first met in an earlier tile of this hop (a few per cent of a hop's edges): that tile's
-    // rank record and the inclusive prefix of the tile in front of it -- up to four edges' loads in flight together.
-    while (farmask) {
-      int32_t kk[4];
-      uint32_t qv[4];
-      unsigned long long tw[4], fb[4], fp[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        kk[u] = farmask ? __ffs((int)farmask) - 1 : -1;
-        if (kk[u] >= 0) farmask &= farmask - 1u;
-        qv[u] = kk[u] >= 0 ? (uint32_t)a[kk[u]][tid] - T : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // (clamped, not predicated: unused entries read record 0 / tile 0's word)
-        const int32_t kt = (int32_t)(qv[u] >> kFinTileLog2) - 1;
-        tw[u] = ld_agent(tstat + (kt > 0 ? kt : 0));
-        fb[u] = ld_agent(fw64 + 2 * (int64_t)(qv[u] >> 6));
-        fp[u] = ld_agent(fw64 + 2 * (int64_t)(qv[u] >> 6) + 1);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (kk[u] < 0) continue;
-        const int32_t kt = (int32_t)(qv[u] >> kFinTileLog2) - 1;
-        uint32_t xk = kt < 0 ? 0u : (uint32_t)tw[u];
-        if (kt >= 0 && (uint32_t)(tw[u] >> 32) != kTilePrefix &&  // (that tile is still looking back: wait for it)
-            !wait_tile_prefix(tstat, kt, xk))
-          atomicOr(&s.st->error, kErrHandoff);
-        a[kk[u]][tid] = (int32_t)(T + xk) + (int32_t)(uint32_t)(fp[u] >> 32) + (int32_t)(uint32_t)fp[u] +
-                        __popcll(fb[u] & ((1ull << (qv[u] & 63u)) - 1ull));
-      }
-    }
-    SPP_GLOBAL int32_t* out = G(s.out_col[h]) + p0;
-    for (int32_t k = 0; k < n; ++k) {
-      const int32_t vv = a[k][tid];
-      int32_t rank = 0;
-      for (int32_t m = 0; m < n; ++m) {
-        const int32_t w = a[m][tid];
-        rank += (w < vv || (w == vv && m < k)) ? 1 : 0;
-      }
-      out[rank] = vv;  // std::sort of the row's local ids (sample_cpu.hpp:126)
-    }
-  }
-}
-
 // generic path: local id of every edge position (sorted afterwards by hipcub)
 __global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                            int32_t h) {
@@ -2316,9 +2004,7 @@ struct spp_sampler {
   SlotState* d_states = nullptr;     // contiguous device states
   SlotState* h_states = nullptr;     // pinned mirror
   int32_t* counts = nullptr;         // [slot][counts_per_slot]: kcount, bfill, ticket counter, ovfc (zeroed per batch, one memset)
-  int64_t counts_per_slot = 0;       // 2 * nb + 1 + SPP_MAX_HOPS (+ pad) + 2 * fin_tiles (the tile status granules)
-  int32_t fin_off[SPP_MAX_HOPS];     // first tile entry of hop h in a slot's tstat / tfirst arrays
-  int64_t fin_tiles = 0;             // entries per slot (all hops)
+  int64_t counts_per_slot = 0;       // 2 * nb + 1 + SPP_MAX_HOPS
   std::shared_ptr<Col32> col32_owner;  // int32 copy of cfg.col_dev, shared by the samplers of one graph
   int32_t* col32 = nullptr;          // = col32_owner->p (NULL: read the int64 array)
   std::shared_ptr<RowStubs> stubs_owner;
@@ -2467,14 +2153,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     rc = dev_alloc(s, &v, sizeof(SlotState) * (size_t)nslots);
     s->d_states = static_cast<SlotState*>(v);
   }
-  // k_hop_finish: per hop one status granule and one first-row entry per 1024-position tile (+ 2: the entry behind the last tile)
-  s->fin_tiles = 0;
-  for (int h = 0; h < H; ++h) {
-    s->fin_off[h] = (int32_t)s->fin_tiles;
-    s->fin_tiles += ceil_div(s->ecap[h], kFinTile) + 2;
-  }
-  const int64_t counts_head = (2 * (int64_t)nb + 1 + SPP_MAX_HOPS + 1) & ~1ll;   // even: the granules behind it are 8-byte aligned
-  s->counts_per_slot = counts_head + 2 * s->fin_tiles;
+  s->counts_per_slot = 2 * (int64_t)nb + 1 + SPP_MAX_HOPS;
   if (rc == SPP_OK) {
     rc = dev_alloc(s, &v, sizeof(int32_t) * (size_t)s->counts_per_slot * (size_t)nslots);
     s->counts = static_cast<int32_t*>(v);
@@ -2506,7 +2185,6 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     A(p.bsum0, int32_t, nblk_max);
     A(p.bsum1, int32_t, nblk_max);
     A(p.known, unsigned long long, (int64_t)nb * s->geom.kcap);
-    A(p.tfirst, int32_t, s->fin_tiles);
     for (int h = 0; h < H; ++h) {
       A(p.out_rowptr[h], int32_t, s->tcap[h] + 1);
       A(p.out_col[h], int32_t, s->ecap[h]);
@@ -2525,7 +2203,6 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     p.bfill = p.kcount + nb;
     p.ctr = p.bfill + nb;
     p.ovfc = p.ctr + 1;
-    p.tstat = reinterpret_cast<unsigned long long*>(p.kcount + counts_head);
     p.st = s->d_states + i;
     sl.host_state = s->h_states + i;
     // per-edge temporaries are separately allocated so the generic path can grow them
@@ -2957,13 +2634,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const int32_t self_prefix = (!s->generic[h] && gt <= 2048) ? 1 : 0;
     if (!self_prefix)
       hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
-    // flag + rows as one pass (k_hop_finish): SPP_FINISH=1.  Built, bit-exact, and measured SLOWER on the big last hop
-    // (289 vs 102 + 93 us per launch of 16 batches: a tile holds its wave slots while it waits for the slowest of its
-    // predecessors' gathers), so the two kernels stay the default (profiles/r05_ab_INDEX.md)
-    static const bool finish_on = [] { const char* e = getenv("SPP_FINISH"); return e && atoi(e) != 0; }();
-    const bool finish = finish_on && !s->generic[h];
-    FuseArgs fa_plain{};
-    fa_plain.tfirst_off = finish ? s->fin_off[h] : -1;
+    const FuseArgs fa_plain{};
     unsigned ge;
     for (int rep = 0; !s->generic[h] && rep < dup.pick - 1; ++rep)
       if (col32 && stubs && s->use_tags)
@@ -2978,13 +2649,15 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // hops.  SPP_FUSE_SCATTER=0: never; 2: wherever the kernel can (measurement aid).
     static const int fuse_mode = [] { const char* e = getenv("SPP_FUSE_SCATTER"); return e ? atoi(e) : 1; }();
     const int64_t tile_cap = (int64_t)kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout));
+    // (dynamic LDS of the fused form: the picks' columns + the staging area; within the 64 KB every kernel may ask for)
+    const unsigned lds_fused = row_lds + (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * (size_t)tile_cap);
     const bool fused = !s->generic[h] && self_prefix && col32 && stubs && s->use_tags && fuse_mode != 0 && f >= 1 &&
-                       nbk <= (unsigned)kMaxBuckets && (fuse_mode >= 2 || tile_cap >= 8 * (int64_t)nbk);
+                       nbk <= (unsigned)kMaxBuckets && lds_fused <= 64u * 1024u &&
+                       (fuse_mode >= 2 || tile_cap >= 8 * (int64_t)nbk);
     if (!s->generic[h]) {
       if (fused) {
-        FuseArgs fa{cb, bucket_cap(pcap, nbk), region, idmask, (int32_t)(row_lds / sizeof(int32_t)), (int32_t)tile_cap,
-                    fa_plain.tfirst_off};
-        const unsigned lds = row_lds + (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * (size_t)tile_cap);
+        FuseArgs fa{cb, bucket_cap(pcap, nbk), region, idmask, (int32_t)(row_lds / sizeof(int32_t)), (int32_t)tile_cap};
+        const unsigned lds = lds_fused;
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, true, true, true>), dim3((gt) * gy), dim3(kNT), lds, st, s->d_slots, GG(gt),
                            col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask, fa);
       } else if (col32 && stubs && s->use_tags)
@@ -3051,17 +2724,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     else
       hipLaunchKernelGGL(k_bucket_dedup<16384>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     const unsigned gflag = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFlagSpan));
-    if (finish) {
-      const unsigned gfin = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kFinTile));
-      hipLaunchKernelGGL(k_hop_finish, dim3((gfin) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gfin), h, f, idmask, row_idbits,
-                         (int32_t)s->tcap[H], pcap_h, s->fin_off[h]);
-    } else {
-      for (int rep = 0; rep < dup.flag; ++rep)
-        hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
-                           (int32_t)s->tcap[H], pcap_h);
-    }
-    if (finish) {
-    } else if (!s->generic[h]) {
+    // (flag + rows as ONE pass with a decoupled look-back over per-tile status granules was built and measured in round 5:
+    // bit-exact, and 289 us against 102 + 93 us per 16-batch launch of the last hop -- a tile holds its wave slots while it
+    // waits for the slowest of its predecessors' gathers; profiles/r05_ab_INDEX.md, commit "Sampling chain experiments")
+    for (int rep = 0; rep < dup.flag; ++rep)
+      hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
+                         (int32_t)s->tcap[H], pcap_h);
+    if (!s->generic[h]) {
       for (int rep = 0; rep < dup.rows; ++rep)
         hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits,
                            (int32_t)s->tcap[h], pcap_h);
@@ -3440,7 +3109,7 @@ extern "C" spp_status spp_sampler_wait(spp_sampler* s, int32_t slot, spp_mfg_cou
   SPP_HIP_TRY(hipEventSynchronize(sl.wait_on));
   sl.waited = true;
   if (sl.host_state->error) {
-    set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws 8=dedup bucket 16=tile hand-off timed out)",
+    set_error("spp_sampler: batch exceeded the slot workspace (error mask %d: 1=edges 2=nodes 4=draws 8=dedup bucket)",
               sl.host_state->error);
     return SPP_ERR_CAPACITY;
   }

@@ -137,6 +137,33 @@ def test_native_exchange_in_process_ranks(P, use_cache, nb, bs, slots, issue, mo
     assert all(stats[r] > 0 for r in range(P))     # counts / ids / rows really travelled
 
 
+@pytest.mark.parametrize("lag", ["0", "1", "2"])
+def test_three_slot_sets_consumer_issued_exchange_under_every_refill_lag(lag, monkeypatch):
+    """The launcher's window is `sets - refill_lag` groups beyond the finished ones (session.hip launch_window; spp.h
+    spp_session_next) and a consumer-issued exchange needs the NEXT group's chain launched (issue_exchanges_up_to(g + 1)
+    with three or more sets): with exactly three sets the two meet.  Every lag must deliver every batch bit for bit and
+    terminate (a window that is one group short would wait for a chain nobody launches)."""
+    from salient_plusplus_amd import fast_sampler as fs
+    monkeypatch.setenv("SPP_EXCHANGE_ISSUE", "consumer")
+    monkeypatch.setenv("SPP_REFILL_LAG", lag)
+    g = _graph()
+    n = g["rowptr"].shape[0] - 1
+    P, offsets = 2, [0, 1400, n]
+    comms = fs.NativeComm.local(P)
+    errors, stats = [], {}
+    # 24 slots = three slot-sets of 8; 41 batches of 4 seeds = six groups, the last one ragged
+    ts = [threading.Thread(target=_run_rank, args=(r, P, comms, g, offsets, True, 41, 4, 24, errors, stats)) for r in range(P)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    hung = [t for t in ts if t.is_alive()]
+    for c in comms:
+        c.close()
+    assert not errors, "\n".join(errors)
+    assert not hung, "rank thread hung"
+
+
 def _run_rank_counting(rank, P, comms, g, offsets, nb, bs, errors, out):
     it = None
     try:

@@ -4,7 +4,7 @@ transport: everything above send / recv / all-gather is the product path) at S-p
 local / cache-hit / fetched composition of its batches and the rows it served, and the per-batch time (ranks share
 one GPU: NOT a performance number).  Run under rocprofv3 (--kernel-trace --stats, or one --pmc counter) for the
 per-kernel figures of k_serve_rows / k_pack_remote_ids / k_gpart_* / k_deliver at that load (tools/r4_exchange_p8.sh).
-usage: exchange_p8.py [P=8] [batches per rank=24] [epochs=2]"""
+usage: [WL=S-papers CACHE_FRAC=0.1 CACHE_STRATEGY=vip] exchange_p8.py [P=8] [batches per rank=24] [epochs=2]"""
 import json
 import os
 os.environ.setdefault("SPP_ALLOW_LOCAL_COMM", "1")   # rehearsal transport: opt-in
@@ -24,6 +24,8 @@ from salient_plusplus_amd.synthetic import make_workload  # noqa: E402
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 EPOCHS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+CACHE_FRAC = float(os.environ.get("CACHE_FRAC", "0.10"))          # of N / P rows, as bench.py --cache-frac
+CACHE_STRATEGY = os.environ.get("CACHE_STRATEGY", "vip")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 wl = make_workload(os.environ.get("WL", "S-products-local"), device=dev)
@@ -47,7 +49,7 @@ def rank_main(r):
         bs = wl.batch_size
         mine = wl.train_idx[(wl.train_idx >= lo) & (wl.train_idx < hi)].contiguous()      # federated seeds
         nb = NB
-        cv = rank_remote_vertices("vip", pb, N, int(0.10 * N / P), rowptr=wl.rowptr, col=wl.col, train_idx=mine,
+        cv = rank_remote_vertices(CACHE_STRATEGY, pb, N, int(CACHE_FRAC * N / P), rowptr=wl.rowptr, col=wl.col, train_idx=mine,
                                   fanouts=wl.fanouts, batch_size=bs).sort().values
         cache = fs.Cache(r, P, cv, wl.x[cv].contiguous())
         in_cache = torch.zeros(N, dtype=torch.bool, device=dev)
@@ -118,7 +120,10 @@ for r in range(P):
           f"bit exact {all(res[(r, e)]['bit_exact'] for e in range(EPOCHS))}; " +
           ", ".join(f"epoch {e}: {res[(r, e)]['us_per_batch']:.0f} us/batch" for e in range(EPOCHS)))
 s = sum(tot)
-summary = {"P": P, "workload": wl.name, "F": F, "row_bytes": 2 * F, "batches_all_ranks": nbatches, "rows_delivered": s,
+summary = {"P": P, "cache_frac": CACHE_FRAC, "cache_strategy": CACHE_STRATEGY, "cache_rows_per_rank": int(CACHE_FRAC * N / P),
+           "exchange_bytes_per_batch_and_rank": [sum(res[(r, e)]["exchange_bytes"][k] for r in range(P) for e in range(EPOCHS)) / max(1, nbatches)
+                                                  for k in (0, 1)],
+           "workload": wl.name, "F": F, "row_bytes": 2 * F, "batches_all_ranks": nbatches, "rows_delivered": s,
            "rows_local": tot[0], "rows_cache": tot[1], "rows_fetched": tot[2], "rows_served": sum(served),
            "frac_local": tot[0] / s, "frac_cache": tot[1] / s, "frac_fetched": tot[2] / s}
 print("EXCHANGE_P8 " + json.dumps(summary), flush=True)
