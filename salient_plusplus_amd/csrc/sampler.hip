@@ -1466,6 +1466,95 @@ __global__ __launch_bounds__(kNT) void k_hop_rows(const SlotPtrs* __restrict__ s
   }
 }
 
+// k_hop_rows with its per-edge arrays moved through LDS in POSITION order (round 5).  A workgroup's 256 rows cover one
+// contiguous run of edge positions [P0, P1); a lane reading its own row straight from HBM issues `f` loads whose 64
+// lanes are 4 f bytes apart -- every load instruction touches 64 f / 16 sectors for 256 useful bytes -- and the sorted
+// row is written back the same way.  Here the run's table values and neighbour entries are fetched by consecutive lanes
+// (consecutive addresses), a lane takes its row out of LDS, the row's sorted local ids replace its table values in place
+// (rows are disjoint), and the run goes out coalesced.  LDS: 8 bytes per edge of the run (<= 256 f edges).
+__global__ __launch_bounds__(kNT) void k_hop_rows_coalesced(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
+                                                             uint32_t idmask, int32_t idbits, int32_t tcap, int64_t pcap,
+                                                             int32_t run_cap) {
+  SPP_GROUP_BLOCK(gg);
+  extern __shared__ int32_t rows_lds[];          // [run_cap] table values -> sorted local ids, [run_cap] neighbour entries
+  uint32_t* lv = reinterpret_cast<uint32_t*>(rows_lds);
+  int32_t* lc = rows_lds + run_cap;
+  __shared__ int32_t run_lo, run_hi;
+  const SlotPtrs& s = slots[gg.first_slot + by_];
+  const SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL int32_t* rp = G(s.out_rowptr[h]);
+  const SPP_GLOBAL uint32_t* evals = G(s.evals);
+  const SPP_GLOBAL int32_t* cval = G(s.cval);
+  const SPP_GLOBAL RankWord* fwords = G(s.fwords);
+  const SPP_GLOBAL int32_t* fsum = G(s.fsum);
+  SPP_GLOBAL int32_t* n_ids = G(s.n_ids);
+  SPP_GLOBAL uint8_t* dtag = G(s.dtag);
+  const int tid = threadIdx.x;
+  const int32_t i = bx_ * kNT + tid;
+  // ---- round trip 1: state words and the row's bounds (index clamped: T is not known yet)
+  const int32_t ic = i < tcap ? i : tcap - 1;
+  const int32_t T = st->cnt[h];
+  const int32_t err0 = st->error;
+  const int32_t p0 = rp[ic];
+  const int32_t p1 = rp[ic + 1];
+  if ((int64_t)bx_ * kNT >= T || err0) return;   // (workgroup-uniform)
+  const bool have = i < T;
+  const int32_t n = have ? p1 - p0 : 0;
+  if (tid == 0) run_lo = p0;
+  if (i == T - 1 || (tid == kNT - 1 && have)) run_hi = p1;   // the last row of the workgroup
+  __syncthreads();
+  const int32_t P0 = run_lo, len = run_hi - run_lo;          // len <= run_cap: <= 256 rows of <= f edges
+  // ---- round trip 2: the run's table values and neighbour entries, coalesced
+  for (int32_t k = tid; k < len; k += kNT) {
+    const int64_t p = (int64_t)P0 + k;
+    lv[k] = evals[p < pcap ? p : pcap - 1];
+    lc[k] = cval[p < pcap ? p : pcap - 1];
+  }
+  __syncthreads();
+  const int32_t off = p0 - P0;
+  // 8 edges at a time: the rank records of the nodes that are new in this hop (others: record 0), then the ids
+  for (int32_t k0 = 0; k0 < n; k0 += 8) {
+    uint32_t v[8], q[8];
+    int32_t fs[8];
+    RankWord rw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = (k0 + u < n) ? lv[off + k0 + u] : 0u;
+      const bool fresh = k0 + u < n && v[u] >= (uint32_t)T;
+      q[u] = fresh ? v[u] - (uint32_t)T : 0u;
+      fs[u] = fsum[q[u] >> 8];
+      rw[u] = load_rank_word(fwords, q[u] >> 6);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u >= n) break;
+      int32_t id = (int32_t)v[u];
+      if (v[u] >= (uint32_t)T) {
+        id = T + fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull));
+        if (q[u] == (uint32_t)(p0 + k0 + u)) {  // n_ids.push_back(c) at its first occurrence
+          const int32_t c = lc[off + k0 + u];
+          n_ids[id] = (int32_t)((uint32_t)c & idmask);
+          if (idbits < 32) dtag[id] = (uint8_t)((uint32_t)c >> idbits);  // the node's degree tag travels with it
+        }
+      }
+      lv[off + k0 + u] = (uint32_t)id;   // (the round's table values are in registers; later rounds' are further on)
+    }
+  }
+  // rank sort of the row (sample_cpu.hpp:126) into its own positions of the run
+  for (int32_t k = 0; k < n; ++k) {
+    const int32_t vv = (int32_t)lv[off + k];
+    int32_t rank = 0;
+    for (int32_t m = 0; m < n; ++m) {
+      const int32_t w = (int32_t)lv[off + m];
+      rank += (w < vv || (w == vv && m < k)) ? 1 : 0;
+    }
+    lc[off + rank] = vv;   // (the neighbour entries have been consumed: their array takes the sorted row)
+  }
+  __syncthreads();
+  SPP_GLOBAL int32_t* out = G(s.out_col[h]) + P0;
+  for (int32_t k = tid; k < len; k += kNT) out[k] = lc[k];
+}
+
 // generic path: local id of every edge position (sorted afterwards by hipcub)
 __global__ __launch_bounds__(kNT) void k_hop_lids_generic(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                            int32_t h) {
@@ -2731,9 +2820,18 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
       hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
                          (int32_t)s->tcap[H], pcap_h);
     if (!s->generic[h]) {
-      for (int rep = 0; rep < dup.rows; ++rep)
-        hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits,
-                           (int32_t)s->tcap[h], pcap_h);
+      // position-ordered staging of the rows' arrays (k_hop_rows_coalesced) while 8 bytes per edge of a workgroup's run fit
+      // 32 KB of LDS (f <= 16); SPP_ROWS_COALESCED=0: the lane-per-row loads
+      static const bool rows_coal = [] { const char* e = getenv("SPP_ROWS_COALESCED"); return !e || atoi(e) != 0; }();
+      const int32_t run_cap = (int32_t)(kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
+      for (int rep = 0; rep < dup.rows; ++rep) {
+        if (rows_coal && f >= 1 && f <= 16)
+          hipLaunchKernelGGL(k_hop_rows_coalesced, dim3((gt) * gy), dim3(kNT), (unsigned)(8 * run_cap), st, s->d_slots, GG(gt), h,
+                             idmask, row_idbits, (int32_t)s->tcap[h], pcap_h, run_cap);
+        else
+          hipLaunchKernelGGL(k_hop_rows, dim3((gt) * gy), dim3(kNT), row_lds, st, s->d_slots, GG(gt), h, idmask, row_idbits,
+                             (int32_t)s->tcap[h], pcap_h);
+      }
     } else {
       const int64_t E = lead.host_state->E[h];
       const int32_t T = lead.host_state->cnt[h];

@@ -3,7 +3,7 @@ transport: everything above send / recv / all-gather is the product path) at S-p
 8-block locality, batch 1024, federated seeds, analytic VIP cache of 10 % of N/P.  Prints, per rank, the
 local / cache-hit / fetched composition of its batches and the rows it served, and the per-batch time (ranks share
 one GPU: NOT a performance number).  Run under rocprofv3 (--kernel-trace --stats, or one --pmc counter) for the
-per-kernel figures of k_serve_rows / k_pack_remote_ids / k_gpart_* / k_deliver at that load (tools/r4_exchange_p8.sh).
+per-kernel figures of k_serve_rows / k_pack_remote_ids / k_gpart_* / k_deliver at that load (tools/exchange_p8.sh).
 usage: [WL=S-papers CACHE_FRAC=0.1 CACHE_STRATEGY=vip] exchange_p8.py [P=8] [batches per rank=24] [epochs=2]"""
 import json
 import os

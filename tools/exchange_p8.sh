@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: [WL=S-papers NB=32 EPOCHS=1] tools/r4_exchange_p8.sh <outdir> <tag e.g. r04_exchange_p8>     (GPU box)
+# usage: [WL=S-papers NB=32 EPOCHS=1] tools/exchange_p8.sh <outdir> <tag e.g. r04_exchange_p8>     (GPU box)
 # Kernel trace + the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes, no tracing domains) of the 8-rank exchange
 # rehearsal (tools/exchange_p8.py) and the per-kernel table (tools/exchange_p8_report.py).
 out=$1; tag=$2

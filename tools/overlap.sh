@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r4_overlap.sh <outdir> [sage|gat]      (GPU box)
+# usage: tools/overlap.sh <outdir> [sage|gat]      (GPU box)
 # Kernel traces of the model-step leg alone and beside the data path + the per-kernel comparison.
 out=$1; arch=${2:-sage}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1

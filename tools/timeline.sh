@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r3_timeline.sh <outdir> "<bench args>" (GPU box): kernel trace of bench.py -> queue timeline, group lag table, trace report, delivery gaps
+# usage: tools/timeline.sh <outdir> "<bench args>" (GPU box): kernel trace of bench.py -> queue timeline, group lag table, trace report, delivery gaps
 out=$1; args=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p "$out"
