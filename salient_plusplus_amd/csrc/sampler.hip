@@ -853,6 +853,8 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    // (the same entries staged through LDS in position order and stored by consecutive lanes -- what k_hop_rows_coalesced does
+    // for its arrays -- measured no gain here: 98 registers instead of 96 = four waves per SIMD instead of five; r05_ab_INDEX.md)
     SPP_GLOBAL int32_t* cv = G(s.cval) + p0;
     for (int32_t k = 0; k < cnt; ++k) cv[k] = chosen[k][tid];
     if constexpr (kFuse) {
@@ -1119,19 +1121,7 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 
   const int32_t shift = g.nb_log2 - cb_log2;
   const int32_t nf = 1 << shift;
   const int32_t fb0 = b << shift;
-  // ---- round trip 1: the state words, the bucket's fill, the fine lists' lengths -- and (round 5) already the bucket's
-  // first kDedupRegs * kNT pairs: a bucket's region starts at b * bcap whatever it holds, so the loads need not wait for
-  // the fill count (entries past it are stale pairs of an earlier hop: dropped below).  One dependent round trip less
-  // per workgroup of a latency-bound kernel.
-  unsigned long long pr[kDedupRegs];
-  {
-    const int32_t r0 = b * bcap;
-#pragma unroll
-    for (int u = 0; u < kDedupRegs; ++u) {
-      const int i = u * kNT + (int)threadIdx.x;
-      pr[u] = bpairs[r0 + (i < bcap ? i : bcap - 1)];
-    }
-  }
+  // ---- round trip 1: the state words, the bucket's bounds and the fine lists' lengths, issued together
   const int32_t err0 = st->error;
   const uint32_t T = (uint32_t)st->cnt[h];
   const uint32_t Tprev = h > 0 ? (uint32_t)st->cnt[h - 1] : 0u;
@@ -1158,12 +1148,18 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 
   }
   if (err0) return;
   const bool work = e1 > e0;  // block-uniform
-  // This hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in registers between the insert pass
-  // and the lookup pass (a bucket holds ~1k edges: usually all of them).
+  // ---- round trip 2.  This hop's candidates: the first kDedupRegs * kNT pairs of the bucket stay in
+  // registers between the insert pass and the lookup pass (a bucket holds ~1k edges: usually all of them).
+  // Index clamped instead of a predicated load, so that the loads issue back to back.
+  // (Round 5 tried these loads in round trip 1 -- a bucket's region starts at b * bcap whatever it holds: one dependent
+  // round trip less per workgroup, no difference in the lone chain or the pipeline, and 4 MB more fetched per batch from
+  // the unfilled half of every region; profiles/r05_ab_INDEX.md.)
+  unsigned long long pr[kDedupRegs];
 #pragma unroll
   for (int u = 0; u < kDedupRegs; ++u) {
     const int i = e0 + u * kNT + threadIdx.x;
-    if (i >= e1) pr[u] = kEmptySlot;
+    const unsigned long long v = bpairs[i < e1 ? i : 0];  // (an empty bucket has e1 == e0 <= i)
+    pr[u] = i < e1 ? v : kEmptySlot;
   }
   if (work)
     for (int i = threadIdx.x; i < NS; i += kNT) tab[i] = kEmptySlot;
