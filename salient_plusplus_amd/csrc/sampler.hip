@@ -174,7 +174,9 @@ struct SlotPtrs {
   // [b * bcap, (b + 1) * bcap); pairs past a bucket's capacity live in the overflow list behind all regions, at
   // [region, region + ovfc[h]) (region = region_for(edge capacity): the same for every hop)
   unsigned long long* bpairs;
-  uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order)
+  uint32_t* inv;       // where k_bucket_scatter put edge position p in bpairs (bucket order); with the tiled flag pass
+                       // (round 5): where it put the pair in STAGING SLOT k of the position's 8 k-edge tile -- see tidx
+  uint16_t* tidx;      // tile-local position of staging slot k (k_bucket_scatter with `tiled`, read by k_hop_flag_tiled)
   uint32_t* res;       // table value of every edge, indexed like bpairs (k_bucket_dedup)
   uint32_t* evals;     // final table value of every edge position: local id (< T) or T + first position
   // first occurrences of the hop (new nodes), by edge position: per 64 positions one 16-byte record
@@ -982,9 +984,12 @@ __global__ __launch_bounds__(kNT) void k_hop_expand_generic(const SlotPtrs* __re
 // Round 4: no counting pass ahead of it.  Bucket b owns the fixed region [b * bcap, (b + 1) * bcap) of bpairs; a
 // tile reserves room for its run with one atomic on the bucket's fill count; pairs that land past the region's end go
 // to the overflow list at [region, ...) one by one (rare: a node reached by hundreds of edges of one hop).
+// tiled = 1 (round 5, with k_hop_flag_tiled): inv is written in the tile's STAGING order -- inv[base + k] = where staging
+// slot k's pair went, consecutive inside a bucket run -- together with tidx[base + k] = the slot's tile-local position, so that
+// the flag pass can fetch the dedup's results as the runs they were written in instead of one random 4-byte word per position.
 __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                          int32_t h, int32_t cb_log2, int32_t bcap, int32_t region,
-                                                         int64_t pcap, uint32_t idmask) {
+                                                         int64_t pcap, uint32_t idmask, int32_t tiled) {
   SPP_GROUP_BLOCK(gg);
   extern __shared__ int32_t sc_lds[];
   const int32_t nbk = 1 << cb_log2;
@@ -1057,20 +1062,25 @@ __global__ __launch_bounds__(kTileNT) void k_bucket_scatter(const SlotPtrs* __re
     sidx[slot] = (uint16_t)li;
     const int32_t rel = slot + delta[b];  // position inside bucket b's region
     if (rel < bcap) {
-      inv[base + li] = (uint32_t)((int32_t)b * bcap + rel);
+      if (!tiled) inv[base + li] = (uint32_t)((int32_t)b * bcap + rel);
     } else {  // the bucket's region is full: the overflow list (one atomic per such pair; rare)
       const int32_t j = __hip_atomic_fetch_add(G(s.ovfc) + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      inv[base + li] = (uint32_t)(region + j);
+      inv[base + (tiled ? slot : li)] = (uint32_t)(region + j);
       bpairs[(int64_t)region + j] = ((unsigned long long)c << 32) | (uint32_t)(base + li);
     }
   }
   __syncthreads();
   const int32_t n_tile = (int32_t)((E - base) < kScatterTile ? (E - base) : kScatterTile);
+  SPP_GLOBAL uint16_t* tidx = G(s.tidx);
   for (int k = threadIdx.x; k < n_tile; k += kTileNT) {
     const uint32_t c = snode[k];
     const int32_t b = (int32_t)bucket_of(c, cb_log2);
     const int32_t rel = k + delta[b];
-    if (rel < bcap) bpairs[(int64_t)b * bcap + rel] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
+    if (rel < bcap) {
+      bpairs[(int64_t)b * bcap + rel] = ((unsigned long long)c << 32) | (uint32_t)(base + sidx[k]);
+      if (tiled) inv[base + k] = (uint32_t)(b * bcap + rel);
+    }
+    if (tiled) tidx[base + k] = sidx[k];
   }
 }
 
@@ -1366,6 +1376,104 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
       s.fwords[blk * (kFlagNT / kWave) + wid] = RankWord{bits[r], (uint32_t)pre, 0u};
       if (wid == kFlagNT / kWave - 1)  // block total, published for the workgroup that will scan
         __hip_atomic_store(&s.fsum[blk], pre + wcnt[r][wid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = take_ticket_is_last(s.ctr, nwg) ? 1 : 0;
+  __syncthreads();
+  if (!is_last) return;
+  const int32_t nblk = (E + 255) / 256;
+  const int32_t nnew = scan_block_sums_acquire(s.fsum, nblk, lscan);
+  if (threadIdx.x == 0) {
+    const int32_t U = st->cnt[h] + nnew;
+    st->cnt[h + 1] = U;
+    st->dbase[h + 1] = st->dbase[h] + (int64_t)(f > 0 ? f : 0) * st->nsmp[h];
+    if (U > ucap) atomicOr(&s.st->error, kErrNodeCap);
+  }
+}
+
+// k_hop_flag over the scatter's 8 k-edge tiles (round 5).  The dedup leaves its results in BUCKET order; k_hop_flag fetches them
+// back as res[inv[p]] -- one random 4-byte word per edge position, 841 k of them per batch in the last hop.  But a tile's pairs
+// of one bucket sit next to each other in res, and the scatter knows the order it staged them in: with `tiled` it writes inv in
+// that staging order (and the slot's tile-local position, 2 bytes), so here consecutive lanes walk consecutive staging slots and
+// read res as the runs it was written in (8 pairs = one 32-byte sector per bucket and tile at papers scale); the values pass
+// through LDS to position order, and everything after that is k_hop_flag's: evals, the first-occurrence bitmap, the rank records
+// and block counts, the last workgroup's scan.  One workgroup per tile (8 rank-block rounds of kFlagSpan positions each).
+constexpr int kFlagTileRounds = kScatterTile / kFlagNT;  // positions per thread
+__global__ __launch_bounds__(kFlagNT) void k_hop_flag_tiled(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
+                                                             int32_t f, int32_t ucap, int64_t pcap) {
+  SPP_GROUP_BLOCK(gg);
+  __shared__ uint32_t vals[kScatterTile];
+  __shared__ unsigned long long wbits[kFlagTileRounds * (kFlagNT / kWave)];
+  __shared__ int32_t wcnt[kFlagTileRounds * (kFlagNT / kWave)];
+  __shared__ int32_t lscan[kFlagNT / kWave + 1];
+  static_assert(kFlagTileRounds * (kFlagNT / kWave) <= kFlagNT, "one thread per bitmap word of the tile");
+  __shared__ int is_last;
+  const SlotPtrs& s = slots[gg.first_slot + by_];
+  SPP_GLOBAL SlotState* st = G(s.st);
+  const SPP_GLOBAL uint32_t* inv = G(s.inv);
+  const SPP_GLOBAL uint16_t* tidx = G(s.tidx);
+  const SPP_GLOBAL uint32_t* res = G(s.res);
+  SPP_GLOBAL uint32_t* evals = G(s.evals);
+  const int64_t base = (int64_t)bx_ * kScatterTile;
+  const int32_t err0 = st->error;
+  const int32_t E = st->E[h];
+  const uint32_t T = (uint32_t)st->cnt[h];
+  if (err0) {
+    if (bx_ == 0 && threadIdx.x == 0) {  // keep the later hops' sizes defined
+      st->cnt[h + 1] = (int32_t)T;
+      st->dbase[h + 1] = st->dbase[h];
+    }
+    return;
+  }
+  const int32_t nwg = E > 0 ? (E + kScatterTile - 1) / kScatterTile : 1;  // workgroup 0 always takes part
+  if ((int32_t)bx_ >= nwg) return;
+  const int32_t n_tile = (int32_t)((E - base) < kScatterTile ? (E - base) : kScatterTile);
+  const int wid = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  // ---- staging order: where each slot's result is, then the result, in rounds of 8 slots per thread (loads batched)
+  for (int32_t k0 = 0; k0 < n_tile; k0 += 8 * kFlagNT) {
+    uint32_t loc[8], v[8];
+    uint16_t pl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int32_t k = k0 + u * kFlagNT + (int32_t)threadIdx.x;
+      const int64_t a = base + (k < n_tile ? k : 0);
+      loc[u] = inv[a];
+      pl[u] = tidx[a];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = res[loc[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u * kFlagNT + (int32_t)threadIdx.x < n_tile) vals[pl[u]] = v[u];
+  }
+  __syncthreads();
+  // ---- position order: round r = rank block r of the tile (256 positions = 4 bitmap words, one per wavefront)
+  for (int r = 0; r < kFlagTileRounds; ++r) {
+    const int64_t p = base + r * kFlagNT + threadIdx.x;
+    bool flag = false;
+    if (p < E) {
+      const uint32_t val = vals[r * kFlagNT + threadIdx.x];
+      evals[p] = val;
+      flag = (val == T + (uint32_t)p);  // first occurrence of a node that is new in this hop
+    }
+    const unsigned long long bits = __ballot(flag);
+    if (lane == 0) {
+      wbits[r * (kFlagNT / kWave) + wid] = bits;
+      wcnt[r * (kFlagNT / kWave) + wid] = __popcll(bits);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kFlagTileRounds * (kFlagNT / kWave)) {  // one thread per bitmap word of the tile
+    const int w = threadIdx.x, blk_l = w / (kFlagNT / kWave), first = blk_l * (kFlagNT / kWave);
+    if (base + (int64_t)blk_l * kFlagNT < E || blk_l == 0) {
+      int32_t pre = 0;
+      for (int k = first; k < w; ++k) pre += wcnt[k];
+      const int64_t blk = (int64_t)bx_ * kFlagTileRounds + blk_l;
+      s.fwords[blk * (kFlagNT / kWave) + (w - first)] = RankWord{wbits[w], (uint32_t)pre, 0u};
+      if (w - first == kFlagNT / kWave - 1)  // block total, published for the workgroup that will scan
+        __hip_atomic_store(&s.fsum[blk], pre + wcnt[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores before the barrier
@@ -2298,6 +2406,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       if (e == hipSuccess) e = hipMalloc((void**)&p.bpairs, sizeof(unsigned long long) * n_bucketed);
       if (e == hipSuccess) e = hipMalloc((void**)&p.evals, sizeof(uint32_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.inv, sizeof(uint32_t) * (size_t)etmp);
+      if (e == hipSuccess) e = hipMalloc((void**)&p.tidx, sizeof(uint16_t) * (size_t)etmp);
       if (e == hipSuccess) e = hipMalloc((void**)&p.res, sizeof(uint32_t) * n_bucketed);
       if (e == hipSuccess) e = hipMalloc((void**)&p.fwords, rank_bytes(etmp));
       if (e == hipSuccess) p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(p.fwords) + rank_off_fsum(etmp));
@@ -2305,7 +2414,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
         set_error("spp_sampler_create: hipMalloc of edge scratch failed: %s", hipGetErrorString(e));
         rc = SPP_ERR_HIP;
       }
-      s->bytes += 12 * etmp + 12 * (int64_t)n_bucketed + (int64_t)rank_bytes(etmp);
+      s->bytes += 14 * etmp + 12 * (int64_t)n_bucketed + (int64_t)rank_bytes(etmp);
     }
     if (rc == SPP_OK && (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&sl.exported, hipEventDisableTiming) != hipSuccess)) {
@@ -2463,6 +2572,7 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
     if (sl.p.bpairs) (void)hipFree(sl.p.bpairs);
     if (sl.p.evals) (void)hipFree(sl.p.evals);
     if (sl.p.inv) (void)hipFree(sl.p.inv);
+    if (sl.p.tidx) (void)hipFree(sl.p.tidx);
     if (sl.p.res) (void)hipFree(sl.p.res);
     if (sl.p.fwords) (void)hipFree(sl.p.fwords);
     if (sl.cub_tmp) (void)hipFree(sl.cub_tmp);
@@ -2517,7 +2627,8 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
     int32_t* old_fsum = sl.p.fsum;
     const int64_t old_cap = sl.etmp_cap;
     (void)hipFree(sl.p.cval); (void)hipFree(sl.p.bpairs); (void)hipFree(sl.p.evals);
-    (void)hipFree(sl.p.inv); (void)hipFree(sl.p.res);
+    (void)hipFree(sl.p.inv); (void)hipFree(sl.p.res); (void)hipFree(sl.p.tidx);
+    sl.p.tidx = nullptr;
     sl.p.cval = nullptr; sl.p.bpairs = nullptr; sl.p.evals = nullptr; sl.p.fwords = nullptr;
     sl.p.inv = nullptr; sl.p.res = nullptr;
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.cval, sizeof(int32_t) * (size_t)cap));
@@ -2526,6 +2637,7 @@ static spp_status grow_edge_scratch(spp_sampler* s, int slot, int h, int64_t nee
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.bpairs, sizeof(unsigned long long) * n_bucketed));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.evals, sizeof(uint32_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.inv, sizeof(uint32_t) * (size_t)cap));
+    SPP_HIP_TRY(hipMalloc((void**)&sl.p.tidx, sizeof(uint16_t) * (size_t)cap));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.res, sizeof(uint32_t) * n_bucketed));
     SPP_HIP_TRY(hipMalloc((void**)&sl.p.fwords, rank_bytes(cap)));
     sl.p.fsum = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(sl.p.fwords) + rank_off_fsum(cap));
@@ -2792,8 +2904,13 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned gsc = (unsigned)std::max<int64_t>(1, ceil_div((int64_t)ge * kNT, kScatterTile));
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
     const int32_t bcap = bucket_cap(pcap_h, nbk);                   // pairs a bucket's region holds
+    // the flag pass over the scatter's tiles (k_hop_flag_tiled) wherever the tile kernel runs on the fast path;
+    // SPP_FLAG_TILED=0: position-ordered inv and one random word per position
+    static const bool flag_tiled_on = [] { const char* e = getenv("SPP_FLAG_TILED"); return !e || atoi(e) != 0; }();
+    const bool flag_tiled = flag_tiled_on && !fused && !s->generic[h];
     if (!fused)
-      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, bcap, region, pcap_h, idmask);
+      hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, bcap, region, pcap_h, idmask,
+                         flag_tiled ? 1 : 0);
     // LDS table of k_bucket_dedup: 2048 / 4096 / 8192 / 16384 slots (any size works: multiply-shift slot index).
     // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
     // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
@@ -2812,9 +2929,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // (flag + rows as ONE pass with a decoupled look-back over per-tile status granules was built and measured in round 5:
     // bit-exact, and 289 us against 102 + 93 us per 16-batch launch of the last hop -- a tile holds its wave slots while it
     // waits for the slowest of its predecessors' gathers; profiles/r05_ab_INDEX.md, commit "Sampling chain experiments")
-    for (int rep = 0; rep < dup.flag; ++rep)
-      hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
-                         (int32_t)s->tcap[H], pcap_h);
+    for (int rep = 0; rep < dup.flag; ++rep) {
+      if (flag_tiled)
+        hipLaunchKernelGGL(k_hop_flag_tiled, dim3((gsc) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gsc), h, f,
+                           (int32_t)s->tcap[H], pcap_h);
+      else
+        hipLaunchKernelGGL(k_hop_flag, dim3((gflag) * gy), dim3(kFlagNT), 0, st, s->d_slots, GG(gflag), h, f,
+                           (int32_t)s->tcap[H], pcap_h);
+    }
     if (!s->generic[h]) {
       // position-ordered staging of the rows' arrays (k_hop_rows_coalesced) while 8 bytes per edge of a workgroup's run fit
       // 32 KB of LDS (f <= 16); SPP_ROWS_COALESCED=0: the lane-per-row loads
