@@ -27,8 +27,12 @@
 //   k_hop_flag      4 edges/lane: results back to position order by reads (res[inv[p]]); bitmap of
 //                                 first occurrences + per-word / per-block counts; the last workgroup
 //                                 (ticket) scans the block counts -> number of new nodes
+//                                 (k_hop_flag_tiled, round 5, behind k_bucket_scatter: the same per 8 k-edge scatter tile,
+//                                 the results fetched in the tile's staging order -- runs instead of random words)
 //   k_hop_rows      lane/target : local ids of the row (rank of a new node = prefix + popcount of the
 //                                 bitmap), n_ids append at first occurrences, LDS rank-sort, out_col
+//                                 (k_hop_rows_coalesced, round 5, fanout <= 16: the workgroup's run of positions through LDS)
+// Round 5: on the small hops k_hop_pick<kFuse> does k_bucket_scatter's work for its own 256 targets' edges.
 // The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
 // one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
 // the ~0.5 ms serial recurrence never sits on the sampling critical path.
@@ -1399,7 +1403,7 @@ __global__ __launch_bounds__(kFlagNT) void k_hop_flag(const SlotPtrs* __restrict
 // that staging order (and the slot's tile-local position, 2 bytes), so here consecutive lanes walk consecutive staging slots and
 // read res as the runs it was written in (8 pairs = one 32-byte sector per bucket and tile at papers scale); the values pass
 // through LDS to position order, and everything after that is k_hop_flag's: evals, the first-occurrence bitmap, the rank records
-// and block counts, the last workgroup's scan.  One workgroup per tile (8 rank-block rounds of kFlagSpan positions each).
+// and block counts, the last workgroup's scan.  One 256-thread workgroup per tile = 32 rank blocks of 256 positions.
 constexpr int kFlagTileRounds = kScatterTile / kFlagNT;  // positions per thread
 __global__ __launch_bounds__(kFlagNT) void k_hop_flag_tiled(const SlotPtrs* __restrict__ slots, GroupGrid gg, int32_t h,
                                                              int32_t f, int32_t ucap, int64_t pcap) {
