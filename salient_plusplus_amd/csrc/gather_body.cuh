@@ -22,6 +22,18 @@ template <> struct vec_of<2> { using type = uint16_t; };
 template <> struct vec_of<1> { using type = uint8_t; };
 
 constexpr int kGatherThreads = 256;
+// stores of the gathered rows: non-temporal (default) or plain (-DSPP_GATHER_STORE_NT=0: measurement aid)
+#ifndef SPP_GATHER_STORE_NT
+#define SPP_GATHER_STORE_NT 1
+#endif
+template <typename T>
+__device__ __forceinline__ void row_store(T v, T* p) {
+#if SPP_GATHER_STORE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 #ifndef SPP_GATHER_UNROLL
 #define SPP_GATHER_UNROLL 4
 #endif
@@ -129,7 +141,7 @@ __device__ __forceinline__ void move_rows_vec_body(KeyFn key_of, PtrFn ptr_of, i
         key_next[u] = key_of(r < n ? r : n - 1);
       }
 #pragma unroll
-      for (int u = 0; u < kGatherUnroll; ++u) __builtin_nontemporal_store(v[u], &d[u][l]);
+      for (int u = 0; u < kGatherUnroll; ++u) row_store(v[u], &d[u][l]);
       continue;
     }
     bool ok[kGatherUnroll];
@@ -144,13 +156,13 @@ __device__ __forceinline__ void move_rows_vec_body(KeyFn key_of, PtrFn ptr_of, i
     }
 #pragma unroll
     for (int u = 0; u < kGatherUnroll; ++u)
-      if (ok[u] && lane_on) __builtin_nontemporal_store(v[u], &d[u][l]);
+      if (ok[u] && lane_on) row_store(v[u], &d[u][l]);
     for (int c = l + lpr; c < chunks; c += lpr) {  // rows wider than one access per lane
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u) v[u] = kNT ? __builtin_nontemporal_load(&s[u][c]) : s[u][c];
 #pragma unroll
       for (int u = 0; u < kGatherUnroll; ++u)
-        if (ok[u]) __builtin_nontemporal_store(v[u], &d[u][c]);
+        if (ok[u]) row_store(v[u], &d[u][c]);
     }
   }
 }
@@ -218,7 +230,7 @@ __device__ __forceinline__ void move_rows_span_body(KeyFn key_of, PtrFn ptr_of, 
         c.z = __shfl(q0, srcB, 64);
         c.w = __shfl(q1, srcB, 64);
         char* span = dst + (base + (int64_t)u * gpb + g0) * row_bytes;
-        if (lane < nchunk) __builtin_nontemporal_store(c, reinterpret_cast<u32x4*>(span) + lane);
+        if (lane < nchunk) row_store(c, reinterpret_cast<u32x4*>(span) + lane);
       }
       continue;
     }
@@ -228,8 +240,8 @@ __device__ __forceinline__ void move_rows_span_body(KeyFn key_of, PtrFn ptr_of, 
       const int64_t r = base + (int64_t)u * gpb + g;
       if (r < n && lane_on) {
         u32x2* d = reinterpret_cast<u32x2*>(dst + r * row_bytes + 16 * l);
-        __builtin_nontemporal_store(u32x2{v[u].x, v[u].y}, d);
-        if (16 * l + 8 < rb) __builtin_nontemporal_store(u32x2{v[u].z, v[u].w}, d + 1);
+        row_store(u32x2{v[u].x, v[u].y}, d);
+        if (16 * l + 8 < rb) row_store(u32x2{v[u].z, v[u].w}, d + 1);
       }
     }
   }
