@@ -2074,8 +2074,16 @@ __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
   }
 }
 
+#ifndef SPP_DELIVER_WAVES
+#define SPP_DELIVER_WAVES 0   // > 0: amdgpu_waves_per_eu for k_deliver (measurement aid: occupancy against registers)
+#endif
+#if SPP_DELIVER_WAVES > 0
+#define SPP_DELIVER_ATTR __attribute__((amdgpu_waves_per_eu(SPP_DELIVER_WAVES, SPP_DELIVER_WAVES)))
+#else
+#define SPP_DELIVER_ATTR
+#endif
 template <int VEC>
-__global__ __launch_bounds__(kGatherThreads) void k_deliver(DeliverArgs a) {
+__global__ __launch_bounds__(kGatherThreads) SPP_DELIVER_ATTR void k_deliver(DeliverArgs a) {
   static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
   deliver_body<VEC>(a, (int)blockIdx.x);
 }
