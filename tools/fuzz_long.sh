@@ -16,7 +16,7 @@ for r in $(seq 1 $rounds); do
     -k test_random_facade_configurations --hypothesis-show-statistics > "$out/fuzz_facade_$r.txt" 2>&1 || { tail -60 "$out/fuzz_facade_$r.txt"; exit 1; }
   echo "round $r facade: $(grep -o '[0-9]* passing' "$out/fuzz_facade_$r.txt")"
   echo "round $r exchange: $(grep -o '[0-9]* passing' "$out/fuzz_exchange_$r.txt")"
-  SPP_FUZZ_RANDOM=1 SPP_FUZZ_EXAMPLES=$n timeout -k 10 300 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -p no:cacheprovider \
+  SPP_FUZZ_RANDOM=1 SPP_FUZZ_EXAMPLES=$n timeout -k 10 300 python3 -m pytest tests/test_gpu_random_kernels.py -x -q -m gpu -p no:cacheprovider \
     -k test_gather_rows_random_shapes --hypothesis-show-statistics > "$out/fuzz_gather_$r.txt" 2>&1 || { tail -40 "$out/fuzz_gather_$r.txt"; exit 1; }
   echo "round $r row gather: $(grep -o '[0-9]* passing' "$out/fuzz_gather_$r.txt")"
 done
