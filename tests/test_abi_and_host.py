@@ -258,3 +258,26 @@ def test_bench_launcher_never_loads_the_gpu_runtime(tmp_path):
     assert dry(2, HIP_VISIBLE_DEVICES="0,7,1")[1]["visible_gpus"] == 1               # stops at the first index that does not exist
     rc, d, _ = dry(2, HIP_VISIBLE_DEVICES="")
     assert rc == 2 and d["visible_gpus"] == 0
+
+
+def test_table_rows_reads_like_the_feature_matrix():
+    """fast_sampler.TableRows (row g1: the batch's features as (resident table, n_id)): sizes, dtype and device read like
+    the matrix x = table[n_id] the reference delivers (fast_sampler.cpp:1004-1016), and the façade's opt-in keyword
+    defaults to the reference behaviour.  (materialize() and the fused first layer are -m gpu tests.)"""
+    import dataclasses
+
+    import torch
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd.fast_trainer.samplers import FastSampler
+    storage = torch.zeros((50, 16), dtype=torch.float16)
+    table = storage[:, :12]                                   # a strided view, as the padded resident table is
+    n_id = torch.tensor([3, 49, 3, 0, 7], dtype=torch.int64)
+    t = fs.TableRows(table, n_id)
+    assert t.shape == torch.Size((5, 12)) and t.size(0) == 5 and t.size(1) == 12 and tuple(t.size()) == (5, 12)
+    assert t.dim() == 2 and t.numel() == 60 and t.dtype == torch.float16
+    assert t.is_cuda is False and t.device == n_id.device
+    assert t.to(None) is t and t.to(n_id.device) is t and t.to(device=torch.device("cpu"), non_blocking=True) is t
+    t.record_stream(None)                                     # host tensors: nothing to record
+    f = {fld.name: fld for fld in dataclasses.fields(FastSampler)}
+    assert list(f)[:3] == ["num_threads", "max_items_in_queue", "cfg"]           # the reference's three (samplers.py:381-399)
+    assert f["table_features"].default is False
