@@ -2951,11 +2951,11 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
     if (!s->generic[h]) {
       // position-ordered staging of the rows' arrays (k_hop_rows_coalesced) while 8 bytes per edge of a workgroup's run fit
-      // 32 KB of LDS (f <= 16); SPP_ROWS_COALESCED=0: the lane-per-row loads
+      // 48 KB of LDS (f <= 24); SPP_ROWS_COALESCED=0: the lane-per-row loads
       static const bool rows_coal = [] { const char* e = getenv("SPP_ROWS_COALESCED"); return !e || atoi(e) != 0; }();
       const int32_t run_cap = (int32_t)(kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
       for (int rep = 0; rep < dup.rows; ++rep) {
-        if (rows_coal && f >= 1 && f <= 16)
+        if (rows_coal && f >= 1 && f <= 24)
           hipLaunchKernelGGL(k_hop_rows_coalesced, dim3((gt) * gy), dim3(kNT), (unsigned)(8 * run_cap), st, s->d_slots, GG(gt), h,
                              idmask, row_idbits, (int32_t)s->tcap[h], pcap_h, run_cap);
         else
