@@ -31,7 +31,7 @@
 //                                 the results fetched in the tile's staging order -- runs instead of random words)
 //   k_hop_rows      lane/target : local ids of the row (rank of a new node = prefix + popcount of the
 //                                 bitmap), n_ids append at first occurrences, LDS rank-sort, out_col
-//                                 (k_hop_rows_coalesced, round 5, fanout <= 16: the workgroup's run of positions through LDS)
+//                                 (k_hop_rows_coalesced, round 5, fanout <= 28: the workgroup's run of positions through LDS)
 // Round 5: on the small hops k_hop_pick<kFuse> does k_bucket_scatter's work for its own 256 targets' edges.
 // The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
 // one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
@@ -2951,11 +2951,11 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
     if (!s->generic[h]) {
       // position-ordered staging of the rows' arrays (k_hop_rows_coalesced) while 8 bytes per edge of a workgroup's run fit
-      // 48 KB of LDS (f <= 24); SPP_ROWS_COALESCED=0: the lane-per-row loads
+      // 56 KB of LDS (f <= 28); SPP_ROWS_COALESCED=0: the lane-per-row loads
       static const bool rows_coal = [] { const char* e = getenv("SPP_ROWS_COALESCED"); return !e || atoi(e) != 0; }();
       const int32_t run_cap = (int32_t)(kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
       for (int rep = 0; rep < dup.rows; ++rep) {
-        if (rows_coal && f >= 1 && f <= 24)
+        if (rows_coal && f >= 1 && f <= 28)
           hipLaunchKernelGGL(k_hop_rows_coalesced, dim3((gt) * gy), dim3(kNT), (unsigned)(8 * run_cap), st, s->d_slots, GG(gt), h,
                              idmask, row_idbits, (int32_t)s->tcap[h], pcap_h, run_cap);
         else
