@@ -2857,12 +2857,15 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // Scatter folded into the pick kernel (kFuse) where a pick workgroup's edges give bucket runs of >= 8 pairs: the small
     // hops.  SPP_FUSE_SCATTER=0: never; 2: wherever the kernel can (measurement aid).
     static const int fuse_mode = [] { const char* e = getenv("SPP_FUSE_SCATTER"); return e ? atoi(e) : 1; }();
+    // (a hop of more edges per batch than this goes through k_bucket_scatter and the tiled flag pass instead: hop 2 of
+    // [20,20,20], 430 k edges, 1.235 -> 1.219 ms per batch; SPP_FUSE_MAX_EDGES)
+    static const int64_t fuse_max_edges = [] { const char* e = getenv("SPP_FUSE_MAX_EDGES"); return e ? atoll(e) : (int64_t)262144; }();
     const int64_t tile_cap = (int64_t)kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout));
     // (dynamic LDS of the fused form: the picks' columns + the staging area; within the 64 KB every kernel may ask for)
     const unsigned lds_fused = row_lds + (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * (size_t)tile_cap);
     const bool fused = !s->generic[h] && self_prefix && col32 && stubs && s->use_tags && fuse_mode != 0 && f >= 1 &&
                        nbk <= (unsigned)kMaxBuckets && lds_fused <= 64u * 1024u &&
-                       (fuse_mode >= 2 || tile_cap >= 8 * (int64_t)nbk);
+                       (fuse_mode >= 2 || (tile_cap >= 8 * (int64_t)nbk && s->ecap[h] <= fuse_max_edges));
     if (!s->generic[h]) {
       if (fused) {
         FuseArgs fa{cb, bucket_cap(pcap, nbk), region, idmask, (int32_t)(row_lds / sizeof(int32_t)), (int32_t)tile_cap};
