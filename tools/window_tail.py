@@ -17,6 +17,18 @@ for r in csv.DictReader(open(path)):
     (dl if "k_deliver" in n else ch).append((s, e))
 dl.sort()
 ch.sort()
+# The trace also holds the priming and warm-up deliveries (3 x slots + W: not a multiple of K), so the windows do not start at
+# delivery 0: a window boundary is where the closing synchronize sits, i.e. the longest gaps between consecutive deliveries --
+# take the offset (mod K) whose boundaries carry the largest total gap over the last windows.  (Round 4 cut the windows at
+# offset 0 and read the synchronize as "a gap before the last two deliveries".)
+tail = dl[-min(len(dl), 12 * K):]
+best, off = -1, 0
+for o in range(K):
+    tot = sum(tail[i][0] - tail[i - 1][1] for i in range(1, len(tail)) if (len(dl) - len(tail) + i) % K == o)
+    if tot > best:
+        best, off = tot, o
+print(f"window boundaries at delivery index = {off} mod {K}")
+dl = dl[off:]
 wins = [dl[i:i + K] for i in range(0, len(dl) - K + 1, K)]
 rows = []
 for w, nxt in zip(wins[-9:-1], wins[-8:]):
