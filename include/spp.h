@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPP_ABI_VERSION 5
+#define SPP_ABI_VERSION 6
 #define SPP_MAX_HOPS 8
 #define SPP_MAX_PARTS 64
 
@@ -134,6 +134,32 @@ typedef struct spp_partition_cfg {
   int64_t cache_map_len;
 } spp_partition_cfg;
 
+/* Which form of the sampling chain a sampler runs.  Every form computes the SAME batches (sample_cpu.hpp:25-143,
+ * fast_sampler.cpp:191-227, :994) -- the forms differ in derived tables and kernel variants only.  By default the
+ * library chooses by itself (sizes, free HBM); these fields pin a choice, and spp_sampler_get_info reports what
+ * was chosen.  Convention for the int32 switches: 0 = automatic (the rule stated; the environment variable named
+ * is honoured, read once at spp_sampler_create), > 0 = on, < 0 = off.  A zero-filled record is "all automatic". */
+typedef struct spp_sampler_opts {
+  int32_t col32;            /* int32 copy of `col` (SPP_COL32; auto: on).  Off: the kernels read the int64 array        */
+  int32_t deg_tags;         /* degree tags in the spare top bits of the int32 entries (SPP_DEG_TAGS; auto: on when
+                               ids leave >= 3 bits spare; used by a sampler only when every later fanout < the cap)     */
+  int32_t row_stubs;        /* 128-byte row-stub table (SPP_ROW_STUBS; auto: when it takes <= 1/4 of the free HBM)      */
+  int32_t rng_arena;        /* mt19937 streams of a whole epoch generated once and kept (auto: when the arena fits
+                               rng_arena_mb and, without an explicit budget, 1/4 of the free HBM); off: per group
+                               into the slots' ping-pong buffers (k_rng_fill)                                          */
+  int64_t rng_arena_mb;     /* budget of that arena in MiB (0: SPP_RNG_ARENA_MB, default 16384)                         */
+  int32_t fuse_scatter;     /* bucket scatter folded into the pick kernel (SPP_FUSE_SCATTER; auto = 1: where a pick
+                               workgroup's edges give bucket runs of >= 8 pairs; 2: wherever the kernel can; off: never) */
+  int32_t flag_tiled;       /* flag pass over the scatter's tiles (SPP_FLAG_TILED; auto: on)                            */
+  int32_t rows_coalesced;   /* rows' per-edge arrays staged through LDS for fanouts <= 28 (SPP_ROWS_COALESCED; auto: on) */
+  int32_t dedup_preread;    /* candidates pre-read the LDS table before their compare-and-swap (SPP_DEDUP_PREREAD;
+                               auto: off)                                                                              */
+  int64_t fuse_max_edges;   /* a hop of more edges per batch is never fused (0: SPP_FUSE_MAX_EDGES, default 262144)     */
+  int64_t initial_edge_cap; /* all-neighbour hops (fanout < 0): starting capacity of the per-edge scratch, grown on
+                               demand (0: min(nnz, 4 Mi))                                                              */
+  int64_t reserved[4];      /* zero                                                                                    */
+} spp_sampler_opts;
+
 typedef struct spp_sampler_cfg {
   const int64_t* rowptr_dev;   /* int64[num_nodes+1], HBM resident           */
   const int64_t* col_dev;      /* int64[nnz], HBM resident                   */
@@ -152,7 +178,31 @@ typedef struct spp_sampler_cfg {
                                   the same generation.  A caller that rewrites the graph in place, or frees it and may get
                                   another graph of equal size at the same address, passes a new value (0 is fine for a
                                   graph that never changes). */
+  spp_sampler_opts opts;       /* chain variants (zero-filled = automatic) */
 } spp_sampler_cfg;
+
+/* What a sampler actually runs -- the outcome of spp_sampler_opts' automatic rules -- and what its one-off tables
+ * cost.  The per-hop arrays are in PROCESSING order (hop 0 = the seeds' neighbours). */
+typedef struct spp_sampler_info {
+  int32_t col32;               /* 1: the kernels read the int32 neighbour array                                        */
+  int32_t deg_tags;            /* 1: degree pass from the nodes' tags (implies col32 and row_stubs)                    */
+  int32_t row_stubs;           /* 1: row-stub table in use                                                             */
+  int32_t rng_arena;           /* 1: epoch arena, 0: per-group generation, -1: no Session has decided yet              */
+  int32_t idbits, tag_cap;     /* bits of a node id inside an int32 entry (32: untagged), largest degree a tag holds   */
+  int32_t num_hops;
+  int32_t dedup_buckets_log2;  /* finest bucket count of the radix-partitioned dedup                                   */
+  int32_t dedup_table_slots;   /* LDS table of k_bucket_dedup                                                          */
+  int32_t generic[SPP_MAX_HOPS];        /* edge-parallel path (fanout < 0 or > 32)                                     */
+  int32_t fused_pick[SPP_MAX_HOPS];     /* k_hop_pick<kFuse> (no k_bucket_scatter launch)                              */
+  int32_t flag_tiled[SPP_MAX_HOPS];     /* k_hop_flag_tiled                                                            */
+  int32_t rows_coalesced[SPP_MAX_HOPS]; /* k_hop_rows_coalesced                                                        */
+  int32_t bucket_log2[SPP_MAX_HOPS];    /* buckets of the hop                                                          */
+  /* one-off set-up work: wall-clock milliseconds THIS sampler spent building a table (0 when it found the table of
+   * an earlier sampler over the same graph, or has none) and the tables' sizes in bytes */
+  double col32_ms, row_stubs_ms, rng_arena_ms;
+  int64_t col32_bytes, row_stubs_bytes, rng_arena_bytes;
+  int64_t rng_arena_batches;   /* streams the arena holds                                                              */
+} spp_sampler_info;
 
 /* counts of one sampled batch; hops in OUTPUT order (outermost first, after the
  * std::reverse at fast_sampler.cpp:224) */
@@ -198,6 +248,9 @@ int64_t spp_sampler_workspace_bytes(const spp_sampler* s);
 void* spp_sampler_deliver_stream(spp_sampler* s);
 /* the configuration the sampler was created with */
 spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out);
+/* the chain variants it runs and the cost of its one-off tables (BLOCKING when the epoch arena is still being
+ * generated: rng_arena_ms is that launch's duration) */
+spp_status spp_sampler_get_info(spp_sampler* s, spp_sampler_info* out);
 
 /* Enqueue the sampling of one batch into `slot` on `stream`.
  * seeds_dev: int64[n_seeds] in HBM.  The RNG stream is mt19937(rng_seed) with

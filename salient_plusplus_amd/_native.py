@@ -23,11 +23,27 @@ class PartitionCfg(C.Structure):
                 ("use_cache", i32), ("cache_map_dev", p), ("cache_map_len", i64)]
 
 
+class SamplerOpts(C.Structure):
+    """spp_sampler_opts: 0 = automatic, > 0 on, < 0 off (include/spp.h)."""
+    _fields_ = [("col32", i32), ("deg_tags", i32), ("row_stubs", i32), ("rng_arena", i32), ("rng_arena_mb", i64),
+                ("fuse_scatter", i32), ("flag_tiled", i32), ("rows_coalesced", i32), ("dedup_preread", i32),
+                ("fuse_max_edges", i64), ("initial_edge_cap", i64), ("reserved", i64 * 4)]
+
+
 class SamplerCfg(C.Structure):
     _fields_ = [("rowptr_dev", p), ("col_dev", p), ("num_nodes", i64), ("nnz", i64),
                 ("num_hops", i32), ("sizes", i64 * SPP_MAX_HOPS), ("max_batch", i64),
                 ("num_slots", i32), ("device", i32), ("replace", i32), ("part", PartitionCfg),
-                ("graph_generation", i64)]
+                ("graph_generation", i64), ("opts", SamplerOpts)]
+
+
+class SamplerInfo(C.Structure):
+    _fields_ = [("col32", i32), ("deg_tags", i32), ("row_stubs", i32), ("rng_arena", i32), ("idbits", i32),
+                ("tag_cap", i32), ("num_hops", i32), ("dedup_buckets_log2", i32), ("dedup_table_slots", i32),
+                ("generic", i32 * SPP_MAX_HOPS), ("fused_pick", i32 * SPP_MAX_HOPS), ("flag_tiled", i32 * SPP_MAX_HOPS),
+                ("rows_coalesced", i32 * SPP_MAX_HOPS), ("bucket_log2", i32 * SPP_MAX_HOPS),
+                ("col32_ms", C.c_double), ("row_stubs_ms", C.c_double), ("rng_arena_ms", C.c_double),
+                ("col32_bytes", i64), ("row_stubs_bytes", i64), ("rng_arena_bytes", i64), ("rng_arena_batches", i64)]
 
 
 class MfgCounts(C.Structure):
@@ -85,6 +101,7 @@ SIGNATURES = {
     "spp_sampler_workspace_bytes": (i64, [p]),
     "spp_sampler_deliver_stream": (p, [p]),
     "spp_sampler_get_cfg": (C.c_int, [p, C.POINTER(SamplerCfg)]),
+    "spp_sampler_get_info": (C.c_int, [p, C.POINTER(SamplerInfo)]),
     "spp_sampler_sample": (C.c_int, [p, i32, p, i64, u32, i64, p]),
     "spp_sampler_wait": (C.c_int, [p, i32, C.POINTER(MfgCounts)]),
     "spp_sampler_export": (C.c_int, [p, i32, C.POINTER(MfgOut), p]),
@@ -167,7 +184,7 @@ def load():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.spp_abi_version() != 5:
+        if L.spp_abi_version() != 6:
             raise SppError("libspp_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -30,7 +30,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags_now = " ".join([HIPCC] + FLAGS)
     if not os.path.exists(stamp) or open(stamp).read() != flags_now:
         force = True
-    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".cuh"))]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     headers += [os.path.join(ROOT, "include", "spp.h"), os.path.abspath(__file__)]
     jobs = []
     for src in SOURCES:

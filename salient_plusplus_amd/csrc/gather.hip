@@ -5,7 +5,7 @@
 // cover one contiguous span of dst, and every group keeps UNROLL independent rows in flight.
 #include "spp_internal.h"
 
-#include "gather_body.cuh"
+#include "gather_body.hip.h"
 
 namespace spp {
 

@@ -1,8 +1,8 @@
 // a1: spp_mt19937_fill -- raw outputs skip .. skip+n-1 of std::mt19937(seed) written to HBM by one
-// workgroup (generator: mt19937.cuh; reference: fast_sampler/sample_cpu.hpp:11, fast_sampler.cpp:994).
+// workgroup (generator: mt19937.hip.h; reference: fast_sampler/sample_cpu.hpp:11, fast_sampler.cpp:994).
 #include "spp_internal.h"
 
-#include "mt19937.cuh"
+#include "mt19937.hip.h"
 
 namespace spp {
 

@@ -6,7 +6,7 @@
 //   assembly             reference fast_trainer/transferers.py:472-486
 #include "spp_internal.h"
 
-#include "partition_common.cuh"
+#include "partition_common.hip.h"
 
 namespace spp {
 

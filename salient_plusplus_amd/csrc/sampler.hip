@@ -33,7 +33,7 @@
 //                                 bitmap), n_ids append at first occurrences, LDS rank-sort, out_col
 //                                 (k_hop_rows_coalesced, round 5, fanout <= 28: the workgroup's run of positions through LDS)
 // Round 5: on the small hops k_hop_pick<kFuse> does k_bucket_scatter's work for its own 256 targets' edges.
-// The batch's mt19937 stream (mt19937.cuh) is produced by k_rng_fill, one workgroup per batch, into
+// The batch's mt19937 stream (mt19937.hip.h) is produced by k_rng_fill, one workgroup per batch, into
 // one of two per-slot buffers: the Session generates it a whole group ahead on its own stream, so
 // the ~0.5 ms serial recurrence never sits on the sampling critical path.
 // The node table is radix-partitioned: 64-bit entries (key<<32 | value) live in per-bucket LDS tables
@@ -49,6 +49,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -58,13 +59,13 @@
 #include <mutex>
 #include <tuple>
 
-#include "gather_body.cuh"
-#include "partition_common.cuh"
+#include "gather_body.hip.h"
+#include "partition_common.hip.h"
 
 #ifndef SPP_TILE_NT
 #define SPP_TILE_NT 1024
 #endif
-#include "mt19937.cuh"
+#include "mt19937.hip.h"
 #include "sampler_internal.h"
 
 namespace spp {
@@ -92,6 +93,9 @@ constexpr int kTileNT = SPP_TILE_NT;         // workgroup size of the two tile k
 constexpr int kScatterTile = 8192;           // edges k_bucket_scatter sorts in LDS per workgroup (48 KB + 8 B per bucket)
 constexpr int kScatterEPT = kScatterTile / kTileNT;
 static_assert(kScatterTile % kTileNT == 0 && kScatterTile <= 65536, "tile-local edge indices are 16 bit");
+#ifndef SPP_DEDUP_SLOTS12
+#define SPP_DEDUP_SLOTS12 3072  // 24 KB: six workgroups per compute unit, a quarter less to clear per bucket (4096: +3.5 % lone chain)
+#endif
 constexpr int kDedupRegs = 6;                // pairs per thread k_bucket_dedup keeps in registers (6 x 256 edges per bucket)
 // Fixed-capacity bucket regions (round 4; a counting pass over the hop's edges used to size them exactly).  A hop
 // with edge capacity pcap and nbk buckets gives every bucket room for twice its share plus 64 pairs; what does not fit
@@ -1726,7 +1730,7 @@ __global__ __launch_bounds__(256) void k_cache_bits(const int32_t* __restrict__ 
 constexpr int kPartRounds = 4;                   // nodes per thread of k_gpart_hist / k_gpart_scatter
 constexpr int kPartSpan = kNT * kPartRounds;     // nodes per workgroup (one row entry of pblk)
 
-// bucket of node v when the cache map entry `m` of v is already in hand (part_bucket_of, partition_common.cuh)
+// bucket of node v when the cache map entry `m` of v is already in hand (part_bucket_of, partition_common.hip.h)
 __device__ __forceinline__ int32_t part_bucket_with(const Offsets& off, int32_t P, int32_t rank, int32_t use_cache,
                                                     int32_t m, int64_t v) {
   if (!use_cache) return owner_of(off, v);
@@ -2158,7 +2162,7 @@ static hipError_t create_data_stream(hipStream_t* st, bool sampling) {
 }
 
 static std::mutex g_col32_mu;
-static std::map<std::tuple<const void*, int64_t, int, int64_t>, std::weak_ptr<Col32>> g_col32;  // (col, nnz, device, generation)
+static std::map<std::tuple<const void*, int64_t, int, int64_t, int>, std::weak_ptr<Col32>> g_col32;  // (col, nnz, device, generation, tagged)
 
 // row stubs of a graph (k_build_stubs), shared like the int32 neighbour array
 struct RowStubs {
@@ -2170,7 +2174,8 @@ struct RowStubs {
     if (p) (void)hipFree(p);
   }
 };
-static std::map<std::tuple<const void*, const void*, int64_t, int, int64_t>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
+// key: (rowptr, col, nnz, device, generation, the int32 array the entries were copied from or NULL)
+static std::map<std::tuple<const void*, const void*, int64_t, int, int64_t, const void*>, std::weak_ptr<RowStubs>> g_stubs;  // guarded by g_col32_mu
 
 struct SlotHost {
   SlotPtrs p{};
@@ -2186,8 +2191,38 @@ struct SlotHost {
   size_t cub_tmp_bytes = 0;
 };
 
+// spp_sampler_opts with every "automatic" resolved (environment read once, at spp_sampler_create)
+struct ResolvedOpts {
+  int col32 = 1;             // 0 / 1
+  int deg_tags = 1;          // 0 / 1 (wanted; whether the ids leave room is decided when the array is built)
+  int row_stubs = -1;        // 0 off, 1 always, -1 when a quarter of the free HBM holds them
+  int rng_arena = -1;        // 0 per-group generation, 1 arena whenever it fits the budget, -1 also the free-HBM rule
+  int64_t rng_arena_words = 0;  // budget
+  int fuse = 1;              // 0 never, 1 rule, 2 wherever the kernel can
+  int64_t fuse_max_edges = 262144;
+  bool flag_tiled = true, rows_coalesced = true, dedup_preread = false;
+};
+
+// what hop h of the chain launches (fixed at creation: spp_sampler_get_info reports it)
+struct HopPlan {
+  bool self_prefix = false;  // k_hop_pick adds up the workgroup sums before its own (else k_hop_scan in between)
+  bool fused = false;        // k_hop_pick<kFuse>: no k_bucket_scatter launch
+  bool flag_tiled = false;   // k_hop_flag_tiled behind k_bucket_scatter
+  bool rows_coal = false;    // k_hop_rows_coalesced
+  unsigned row_lds = 0;      // dynamic LDS of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
+  unsigned lds_fused = 0;    // dynamic LDS of the fused pick
+  int64_t tile_cap = 0;
+};
+
 struct spp_sampler {
   spp_sampler_cfg cfg{};
+  ResolvedOpts opt{};
+  HopPlan plan[SPP_MAX_HOPS];
+  int rng_arena_decision = -1;       // spp_sampler_info.rng_arena
+  double col32_ms = 0, stubs_ms = 0; // wall clock this sampler spent building the shared tables
+  hipEvent_t arena_t0 = nullptr, arena_t1 = nullptr;  // around the arena's generation launch
+  double rng_arena_ms = 0;
+  bool arena_timed = false;          // arena_t0/t1 hold a generation that has not been read yet
   int64_t tcap[SPP_MAX_HOPS + 1];   // node capacity before hop h (tcap[H] = Ucap)
   int64_t ecap[SPP_MAX_HOPS];
   int64_t dcap = 0;
@@ -2286,6 +2321,37 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
   auto* s = new spp_sampler();
   s->cfg = *cfg;
   if (const char* e = getenv("SPP_XCD_AFFINITY")) s->xcd_affinity = atoi(e) != 0;
+  {
+    // chain variants: a field of cfg->opts when set, else the environment variable, else the rule (include/spp.h)
+    const spp_sampler_opts& o = cfg->opts;
+    auto env_int = [](const char* name, long long dflt) -> long long {
+      const char* e = getenv(name);
+      return e && *e ? atoll(e) : dflt;
+    };
+    auto sw = [&](int32_t field, const char* name, int dflt) -> int {  // on/off switch -> 0 / 1
+      if (field) return field > 0 ? 1 : 0;
+      return env_int(name, dflt) != 0 ? 1 : 0;
+    };
+    ResolvedOpts& r = s->opt;
+    r.col32 = sw(o.col32, "SPP_COL32", 1);
+    r.deg_tags = sw(o.deg_tags, "SPP_DEG_TAGS", 1);
+    if (o.row_stubs) r.row_stubs = o.row_stubs > 0 ? 1 : 0;
+    else {
+      const long long m = env_int("SPP_ROW_STUBS", -1);
+      r.row_stubs = m < 0 ? -1 : (m > 0 ? 1 : 0);
+    }
+    const bool env_budget = getenv("SPP_RNG_ARENA_MB") != nullptr;
+    const long long mb = o.rng_arena_mb > 0 ? o.rng_arena_mb : env_int("SPP_RNG_ARENA_MB", 16384);
+    r.rng_arena_words = (mb < 0 ? 0 : mb) * (int64_t)(1 << 20) / 4;
+    if (o.rng_arena) r.rng_arena = o.rng_arena > 0 ? 1 : 0;
+    else r.rng_arena = (o.rng_arena_mb > 0 || env_budget) ? 1 : -1;   // an explicit budget replaces the free-HBM rule
+    if (o.fuse_scatter) r.fuse = o.fuse_scatter < 0 ? 0 : std::min(o.fuse_scatter, 2);
+    else r.fuse = (int)std::max<long long>(0, std::min<long long>(2, env_int("SPP_FUSE_SCATTER", 1)));
+    r.fuse_max_edges = o.fuse_max_edges > 0 ? o.fuse_max_edges : env_int("SPP_FUSE_MAX_EDGES", 262144);
+    r.flag_tiled = sw(o.flag_tiled, "SPP_FLAG_TILED", 1) != 0;
+    r.rows_coalesced = sw(o.rows_coalesced, "SPP_ROWS_COALESCED", 1) != 0;
+    r.dedup_preread = sw(o.dedup_preread, "SPP_DEDUP_PREREAD", 0) != 0;
+  }
   const int H = cfg->num_hops;
   const int64_t node_bound = cfg->num_nodes + cfg->max_batch;  // distinct nodes + duplicated seeds
   s->tcap[0] = cfg->max_batch;
@@ -2300,7 +2366,8 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       s->dcap += f * s->tcap[h];
     } else {
       // all-neighbour hop: sized on demand (host sync per hop); start small
-      s->ecap[h] = std::min<int64_t>(std::max<int64_t>(cfg->nnz, 1), 1 << 22);
+      s->ecap[h] = cfg->opts.initial_edge_cap > 0 ? cfg->opts.initial_edge_cap
+                                                  : std::min<int64_t>(std::max<int64_t>(cfg->nnz, 1), 1 << 22);
       s->tcap[h + 1] = node_bound;
     }
     etmp = std::max(etmp, s->ecap[h]);
@@ -2434,70 +2501,71 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       rc = SPP_ERR_HIP;
     }
   }
-  if (rc == SPP_OK && cfg->nnz > 0) {
-    const char* e = getenv("SPP_COL32");
-    if (!e || atoi(e) != 0) {
-      std::lock_guard<std::mutex> lk(g_col32_mu);
-      const auto key = std::make_tuple((const void*)cfg->col_dev, cfg->nnz, (int)cfg->device, cfg->graph_generation);
-      std::shared_ptr<Col32> c = g_col32[key].lock();
-      if (!c) {
-        c = std::make_shared<Col32>();
-        c->device = cfg->device;
-        // + slack: k_hop_pick reads rows in 16-byte pieces that may run past the last row's end
-        if (hipMalloc((void**)&c->p, sizeof(int32_t) * ((size_t)cfg->nnz + 16)) != hipSuccess) {
-          c->p = nullptr;
-          set_error("spp_sampler_create: hipMalloc of the int32 neighbour array failed");
-          rc = SPP_ERR_HIP;
+  if (rc == SPP_OK && cfg->nnz > 0 && s->opt.col32) {
+    std::lock_guard<std::mutex> lk(g_col32_mu);
+    // degree tags in the spare top bits (deg_tags off: plain ids), when at least 3 bits are spare
+    int idbits = 1;
+    while (idbits < 32 && ((int64_t)1 << idbits) < cfg->num_nodes) ++idbits;
+    const bool want_tags = s->opt.deg_tags && idbits <= 29;
+    const auto key = std::make_tuple((const void*)cfg->col_dev, cfg->nnz, (int)cfg->device, cfg->graph_generation,
+                                     want_tags ? 1 : 0);
+    std::shared_ptr<Col32> c = g_col32[key].lock();
+    if (!c) {
+      const auto t0 = std::chrono::steady_clock::now();
+      c = std::make_shared<Col32>();
+      c->device = cfg->device;
+      // + slack: k_hop_pick reads rows in 16-byte pieces that may run past the last row's end
+      if (hipMalloc((void**)&c->p, sizeof(int32_t) * ((size_t)cfg->nnz + 16)) != hipSuccess) {
+        c->p = nullptr;
+        set_error("spp_sampler_create: hipMalloc of the int32 neighbour array failed");
+        rc = SPP_ERR_HIP;
+      } else {
+        uint8_t* deg8 = nullptr;
+        if (want_tags && hipMalloc((void**)&deg8, (size_t)cfg->num_nodes) == hipSuccess) {
+          const int tagbits = std::min(32 - idbits, 8);
+          c->idbits = idbits;
+          c->cap = (1u << tagbits) - 1u;
+          hipLaunchKernelGGL(k_build_deg8, dim3(256 * 16), dim3(256), 0, nullptr, cfg->rowptr_dev, cfg->num_nodes, deg8);
+          hipLaunchKernelGGL(k_narrow_col_tagged, dim3(256 * 32), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, deg8,
+                             idbits, c->cap, c->p);
         } else {
-          // degree tags in the spare top bits (SPP_DEG_TAGS=0: plain ids), when at least 3 bits are spare
-          int idbits = 1;
-          while (idbits < 32 && ((int64_t)1 << idbits) < cfg->num_nodes) ++idbits;
-          const char* et = getenv("SPP_DEG_TAGS");
-          uint8_t* deg8 = nullptr;
-          if ((!et || atoi(et) != 0) && idbits <= 29 &&
-              hipMalloc((void**)&deg8, (size_t)cfg->num_nodes) == hipSuccess) {
-            const int tagbits = std::min(32 - idbits, 8);
-            c->idbits = idbits;
-            c->cap = (1u << tagbits) - 1u;
-            hipLaunchKernelGGL(k_build_deg8, dim3(256 * 16), dim3(256), 0, nullptr, cfg->rowptr_dev, cfg->num_nodes, deg8);
-            hipLaunchKernelGGL(k_narrow_col_tagged, dim3(256 * 32), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, deg8,
-                               idbits, c->cap, c->p);
-          } else {
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(k_narrow_col, dim3(256 * 16), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, c->p);
-          }
-          if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            set_error("spp_sampler_create: narrowing the neighbour array failed");
-            rc = SPP_ERR_HIP;
-          }
-          if (deg8) (void)hipFree(deg8);
+          (void)hipGetLastError();
+          hipLaunchKernelGGL(k_narrow_col, dim3(256 * 16), dim3(256), 0, nullptr, cfg->col_dev, cfg->nnz, c->p);
         }
-        if (rc == SPP_OK) g_col32[key] = c;
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+          set_error("spp_sampler_create: narrowing the neighbour array failed");
+          rc = SPP_ERR_HIP;
+        }
+        if (deg8) (void)hipFree(deg8);
       }
       if (rc == SPP_OK) {
-        s->col32_owner = c;
-        s->col32 = c->p;
-        s->idbits = c->idbits;
-        s->idmask = c->idbits < 32 ? ((1u << c->idbits) - 1u) : 0xffffffffu;
-        s->bytes += (int64_t)sizeof(int32_t) * cfg->nnz;
+        g_col32[key] = c;
+        s->col32_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       }
+    }
+    if (rc == SPP_OK) {
+      s->col32_owner = c;
+      s->col32 = c->p;
+      s->idbits = c->idbits;
+      s->idmask = c->idbits < 32 ? ((1u << c->idbits) - 1u) : 0xffffffffu;
+      s->bytes += (int64_t)sizeof(int32_t) * cfg->nnz;
     }
   }
   // Row stubs (128 B per node): SPP_ROW_STUBS=0 off, =1 always; default: when they take at most a quarter
   // of the memory that is free right now (the caller may still have tensors to place).  Only the fast path
   // uses them.
-  if (rc == SPP_OK && cfg->nnz > 0 && cfg->num_nodes > 0 && !s->any_generic) {
-    const char* e = getenv("SPP_ROW_STUBS");
-    const int mode = e ? atoi(e) : -1;
+  if (rc == SPP_OK && cfg->nnz > 0 && cfg->num_nodes > 0 && !s->any_generic && s->opt.row_stubs != 0) {
+    const int mode = s->opt.row_stubs;
     const size_t need = sizeof(int32_t) * kStubInts * (size_t)cfg->num_nodes;
     std::lock_guard<std::mutex> lk(g_col32_mu);
     const auto key = std::make_tuple((const void*)cfg->rowptr_dev, (const void*)cfg->col_dev, cfg->nnz, (int)cfg->device,
-                                    cfg->graph_generation);
+                                    cfg->graph_generation, (const void*)s->col32);
     std::shared_ptr<RowStubs> c = g_stubs[key].lock();
-    if (!c && mode != 0) {
+    if (!c) {
       size_t free_b = 0, total_b = 0;
       const bool room = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4);
       if (room) {
+        const auto t0 = std::chrono::steady_clock::now();
         c = std::make_shared<RowStubs>();
         c->device = cfg->device;
         if (hipMalloc((void**)&c->p, need) != hipSuccess) {
@@ -2518,6 +2586,7 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
             rc = SPP_ERR_HIP;
           } else {
             g_stubs[key] = c;
+            s->stubs_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
           }
         }
       }
@@ -2548,6 +2617,58 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
                 "(this library targets gfx950)", have, need + 1024);
       (void)hipGetLastError();
       rc = SPP_ERR_HIP;
+    }
+  }
+  if (rc == SPP_OK) {
+    // what every hop launches (spp_sampler_get_info reports it)
+    int lds_limit = 0;
+    (void)hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device);
+    hipFuncAttributes fattr{};
+    const void* fused_fn = reinterpret_cast<const void*>(&k_hop_pick<false, int32_t, true, true, true>);
+    const int lds_static = hipFuncGetAttributes(&fattr, fused_fn) == hipSuccess ? (int)fattr.sharedSizeBytes : 8 * 1024;
+    (void)hipGetLastError();
+    unsigned lds_fused_max = 0;
+    for (int h = 0; h < H; ++h) {
+      HopPlan& pl = s->plan[h];
+      const int32_t f = (int32_t)cfg->sizes[h];
+      const int32_t fc = std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout));
+      const int64_t gt = std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
+      pl.row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)fc);
+      pl.self_prefix = !s->generic[h] && gt <= 2048;
+      // Scatter folded into the pick kernel (kFuse) where a pick workgroup's edges give bucket runs of >= 8 pairs: the
+      // small hops (a hop of more than fuse_max_edges edges per batch goes through k_bucket_scatter and the tiled flag
+      // pass instead: hop 2 of [20,20,20], 430 k edges, 1.235 -> 1.219 ms per batch).  Its dynamic LDS -- the picks'
+      // columns and the staging area -- stays within 64 KB (fanouts <= 25), and together with the kernel's static arrays
+      // (a few KB more: up to ~69 KB in all) within what gfx950 gives one workgroup.
+      const unsigned nbk = 1u << s->cb_log2[h];
+      pl.tile_cap = (int64_t)kNT * fc;
+      pl.lds_fused = pl.row_lds + (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * (size_t)pl.tile_cap);
+      pl.fused = !s->generic[h] && pl.self_prefix && s->col32 && s->stubs && s->use_tags && s->opt.fuse != 0 && f >= 1 &&
+                 nbk <= (unsigned)kMaxBuckets && pl.lds_fused <= 64u * 1024u &&
+                 (int64_t)pl.lds_fused + lds_static <= (int64_t)lds_limit &&
+                 (s->opt.fuse >= 2 || (pl.tile_cap >= 8 * (int64_t)nbk && s->ecap[h] <= s->opt.fuse_max_edges));
+      if (pl.fused) lds_fused_max = std::max(lds_fused_max, pl.lds_fused);
+      // the flag pass over the scatter's tiles wherever the tile kernel runs on the fast path
+      pl.flag_tiled = s->opt.flag_tiled && !pl.fused && !s->generic[h];
+      // position-ordered staging of the rows' arrays while 8 bytes per edge of a workgroup's run fit 56 KB of LDS
+      pl.rows_coal = !s->generic[h] && s->opt.rows_coalesced && f >= 1 && f <= 28;
+    }
+    if (lds_fused_max > 0) {
+      // the kernel's dynamic-LDS ceiling is a per-process attribute: only ever raised
+      static unsigned fused_lds_attr = 0;  // guarded by g_col32_mu
+      std::lock_guard<std::mutex> lk(g_col32_mu);
+      bool ok = lds_fused_max <= fused_lds_attr;
+      if (!ok && hipFuncSetAttribute(fused_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused_max) == hipSuccess) {
+        fused_lds_attr = lds_fused_max;
+        ok = true;
+      }
+      (void)hipGetLastError();
+      if (!ok)  // (up to 64 KB a launch needs no attribute) beyond that those hops keep the tile kernel
+        for (int h = 0; h < H; ++h)
+          if (s->plan[h].fused && s->plan[h].lds_fused > 64u * 1024u) {
+            s->plan[h].fused = false;
+            s->plan[h].flag_tiled = s->opt.flag_tiled;
+          }
     }
   }
   // work streams are created on first use, right after this one (only as many as slot-sets are used)
@@ -2592,6 +2713,8 @@ extern "C" void spp_sampler_destroy(spp_sampler* s) {
   if (s->rng_arena) (void)hipFree(s->rng_arena);
   if (s->rng_arena_seeds_dev) (void)hipFree(s->rng_arena_seeds_dev);
   if (s->rng_arena_ready) (void)hipEventDestroy(s->rng_arena_ready);
+  if (s->arena_t0) (void)hipEventDestroy(s->arena_t0);
+  if (s->arena_t1) (void)hipEventDestroy(s->arena_t1);
   if (s->inputs_ready) (void)hipEventDestroy(s->inputs_ready);
   if (s->cache_bits_ready) (void)hipEventDestroy(s->cache_bits_ready);
   if (s->cache_bits) (void)hipFree(s->cache_bits);
@@ -2625,6 +2748,44 @@ extern "C" void* spp_sampler_deliver_stream(spp_sampler* s) { return s ? (void*)
 extern "C" spp_status spp_sampler_get_cfg(const spp_sampler* s, spp_sampler_cfg* out) {
   SPP_REQUIRE(s && out, "spp_sampler_get_cfg: NULL argument");
   *out = s->cfg;
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sampler_get_info(spp_sampler* s, spp_sampler_info* out) {
+  SPP_REQUIRE(s && out, "spp_sampler_get_info: NULL argument");
+  memset(out, 0, sizeof(*out));
+  const int H = s->cfg.num_hops;
+  out->col32 = s->col32 ? 1 : 0;
+  out->deg_tags = s->use_tags ? 1 : 0;
+  out->row_stubs = s->stubs ? 1 : 0;
+  out->rng_arena = s->rng_arena_decision;
+  out->idbits = s->idbits;
+  out->tag_cap = (int32_t)s->tag_cap;
+  out->num_hops = H;
+  out->dedup_buckets_log2 = s->geom.nb_log2;
+  out->dedup_table_slots = s->lds_log2 == 11 ? 2048 : (s->lds_log2 == 12 ? SPP_DEDUP_SLOTS12 : (s->lds_log2 == 13 ? 8192 : 16384));
+  for (int h = 0; h < H; ++h) {
+    out->generic[h] = s->generic[h] ? 1 : 0;
+    out->fused_pick[h] = s->plan[h].fused ? 1 : 0;
+    out->flag_tiled[h] = s->plan[h].flag_tiled ? 1 : 0;
+    out->rows_coalesced[h] = s->plan[h].rows_coal ? 1 : 0;
+    out->bucket_log2[h] = s->cb_log2[h];
+  }
+  if (s->arena_timed) {
+    (void)hipSetDevice(s->cfg.device);
+    float ms = 0.f;
+    if (hipEventSynchronize(s->arena_t1) == hipSuccess && hipEventElapsedTime(&ms, s->arena_t0, s->arena_t1) == hipSuccess)
+      s->rng_arena_ms = ms;
+    (void)hipGetLastError();
+    s->arena_timed = false;
+  }
+  out->col32_ms = s->col32_ms;
+  out->row_stubs_ms = s->stubs_ms;
+  out->rng_arena_ms = s->rng_arena_ms;
+  out->col32_bytes = s->col32 ? (int64_t)sizeof(int32_t) * (s->cfg.nnz + 16) : 0;
+  out->row_stubs_bytes = s->stubs ? (int64_t)sizeof(int32_t) * kStubInts * s->cfg.num_nodes : 0;
+  out->rng_arena_bytes = 4 * s->rng_arena_words;
+  out->rng_arena_batches = (int64_t)s->rng_arena_seeds.size();
   return SPP_OK;
 }
 
@@ -2717,15 +2878,12 @@ spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, 
   *stride = 0;
   *ready = nullptr;
   if (s->dcap <= 0 || nb <= 0) return SPP_OK;
-  static const int64_t budget_words = [] {
-    const char* e = getenv("SPP_RNG_ARENA_MB");
-    const int64_t mb = e ? atoll(e) : 16384;
-    return (mb < 0 ? 0 : mb) * (int64_t)(1 << 20) / 4;
-  }();
+  s->rng_arena_decision = 0;
+  if (s->opt.rng_arena == 0) return SPP_OK;   // spp_sampler_opts.rng_arena off: per-group generation (k_rng_fill)
   const int64_t stride_w = (s->dcap + kMtSlack + 31) / 32 * 32;  // 128-B aligned streams
   const int64_t need = stride_w * nb;
-  if (need > budget_words) return SPP_OK;
-  if (need > s->rng_arena_words && !getenv("SPP_RNG_ARENA_MB")) {
+  if (need > s->opt.rng_arena_words) return SPP_OK;
+  if (need > s->rng_arena_words && s->opt.rng_arena < 0) {
     // no explicit budget: a new arena may take at most a quarter of the HBM that is free right now (the row stubs
     // follow the same rule); otherwise the streams are generated per group into the slots
     size_t free_b = 0, total_b = 0;
@@ -2759,9 +2917,16 @@ spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, 
     if (!s->rng_arena_ready) SPP_HIP_TRY(hipEventCreateWithFlags(&s->rng_arena_ready, hipEventDisableTiming));
     SPP_HIP_TRY(hipMemcpyAsync(s->rng_arena_seeds_dev, seeds, sizeof(uint32_t) * (size_t)nb, hipMemcpyHostToDevice, st));
     SPP_HIP_TRY(hipStreamSynchronize(st));  // `seeds` is the caller's pageable memory
+    if (!s->arena_t0) {
+      SPP_HIP_TRY(hipEventCreate(&s->arena_t0));
+      SPP_HIP_TRY(hipEventCreate(&s->arena_t1));
+    }
+    SPP_HIP_TRY(hipEventRecord(s->arena_t0, st));
     hipLaunchKernelGGL(k_rng_arena, dim3((unsigned)nb), dim3(kMtThreads), 0, st, s->rng_arena, stride_w,
                        s->rng_arena_seeds_dev, s->dcap);
     SPP_HIP_TRY(hipGetLastError());
+    SPP_HIP_TRY(hipEventRecord(s->arena_t1, st));
+    s->arena_timed = true;
     SPP_HIP_TRY(hipEventRecord(s->rng_arena_ready, st));
     s->rng_arena_stride = stride_w;
     s->rng_arena_seeds.assign(seeds, seeds + nb);
@@ -2769,6 +2934,7 @@ spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, 
   *base = s->rng_arena;
   *stride = stride_w;
   *ready = s->rng_arena_ready;
+  s->rng_arena_decision = 1;
   return SPP_OK;
 }
 
@@ -2829,8 +2995,9 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
   for (int h = 0; h < H; ++h) {
     const int32_t f = (int32_t)s->cfg.sizes[h];
     const unsigned gt = (unsigned)std::max<int64_t>(1, ceil_div(s->tcap[h], kNT));
+    const HopPlan& pl = s->plan[h];
     // per-lane row staging of k_hop_pick / k_hop_rows: max(f, 1) columns of kNT ints
-    const unsigned row_lds = (unsigned)(sizeof(int32_t) * kNT * (size_t)std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
+    const unsigned row_lds = pl.row_lds;
     for (int rep = 0; h > 0 && rep < dup.count; ++rep) {
       const unsigned gc = (gt + kNT / kWave - 1) / (kNT / kWave);  // one wavefront per 256 targets
       hipLaunchKernelGGL(k_hop_count, dim3((gc) * gy), dim3(kNT), 0, st, s->d_slots, GG(gc), rowptr, stubs, s->use_tags ? 1 : 0, h, f, replace, (int32_t)s->tcap[h]);
@@ -2840,7 +3007,7 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
         s->generic[h] ? 0x7fffffff : (int32_t)std::min<int64_t>(lead.ecap_dyn[h], 0x7fffffff);
     // fast path: k_hop_pick adds up the workgroup sums before its own by itself (a few loads per lane up to
     // ~2k workgroups per batch); otherwise a single-workgroup scan launch in between
-    const int32_t self_prefix = (!s->generic[h] && gt <= 2048) ? 1 : 0;
+    const int32_t self_prefix = pl.self_prefix ? 1 : 0;
     if (!self_prefix)
       hipLaunchKernelGGL(k_hop_scan, dim3((1) * gy), dim3(kScanNT), 0, st, s->d_slots, GG(1), h, f, ecap_dev, s->dcap);
     const FuseArgs fa_plain{};
@@ -2853,22 +3020,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const int32_t cb = s->cb_log2[h];
     const unsigned nbk = 1u << cb;
     const int64_t pcap = std::max<int64_t>(1, s->generic[h] ? 0 : s->ecap[h]);   // (generic hops: set below, after the host sync)
-    const int32_t region = (int32_t)region_for(lead.etmp_cap);       // first position of the overflow list
-    // Scatter folded into the pick kernel (kFuse) where a pick workgroup's edges give bucket runs of >= 8 pairs: the small
-    // hops.  SPP_FUSE_SCATTER=0: never; 2: wherever the kernel can (measurement aid).
-    static const int fuse_mode = [] { const char* e = getenv("SPP_FUSE_SCATTER"); return e ? atoi(e) : 1; }();
-    // (a hop of more edges per batch than this goes through k_bucket_scatter and the tiled flag pass instead: hop 2 of
-    // [20,20,20], 430 k edges, 1.235 -> 1.219 ms per batch; SPP_FUSE_MAX_EDGES)
-    static const int64_t fuse_max_edges = [] { const char* e = getenv("SPP_FUSE_MAX_EDGES"); return e ? atoll(e) : (int64_t)262144; }();
-    const int64_t tile_cap = (int64_t)kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout));
-    // (dynamic LDS of the fused form: the picks' columns + the staging area; within the 64 KB every kernel may ask for)
-    const unsigned lds_fused = row_lds + (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * (size_t)tile_cap);
-    const bool fused = !s->generic[h] && self_prefix && col32 && stubs && s->use_tags && fuse_mode != 0 && f >= 1 &&
-                       nbk <= (unsigned)kMaxBuckets && lds_fused <= 64u * 1024u &&
-                       (fuse_mode >= 2 || (tile_cap >= 8 * (int64_t)nbk && s->ecap[h] <= fuse_max_edges));
+    // scatter folded into the pick kernel on the small hops, chosen at creation (HopPlan; spp_sampler_opts.fuse_scatter)
+    const bool fused = pl.fused;
+    const int64_t tile_cap = pl.tile_cap;
+    const unsigned lds_fused = pl.lds_fused;
     if (!s->generic[h]) {
       if (fused) {
-        FuseArgs fa{cb, bucket_cap(pcap, nbk), region, idmask, (int32_t)(row_lds / sizeof(int32_t)), (int32_t)tile_cap};
+        // (first position of the overflow list: a sampler with a fused hop has no generic hop, its scratch never grows)
+        FuseArgs fa{cb, bucket_cap(pcap, nbk), (int32_t)region_for(lead.etmp_cap), idmask, (int32_t)(row_lds / sizeof(int32_t)), (int32_t)tile_cap};
         const unsigned lds = lds_fused;
         hipLaunchKernelGGL((k_hop_pick<false, int32_t, true, true, true>), dim3((gt) * gy), dim3(kNT), lds, st, s->d_slots, GG(gt),
                            col32, stubs, h, f, replace, self_prefix, ecap_dev, s->dcap, (int32_t)s->tcap[h], pick_mask, fa);
@@ -2905,13 +3064,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
         hipLaunchKernelGGL(k_hop_expand_generic<int64_t>, dim3((ge) * gy), dim3(kNT), 0, st, s->d_slots, GG(ge), col,
                            h, f, replace, idmask);
     }
+    // first position of the overflow list behind the bucket regions -- AFTER the generic branch, which may just have
+    // grown the per-edge scratch (the regions are sized from the hop's edge count: an overflow list placed by the old
+    // capacity would lie inside them)
+    const int32_t region = (int32_t)region_for(lead.etmp_cap);
     // dedup: regroup into fixed-capacity bucket regions -> one workgroup per bucket with an LDS table
     // bit 0: the known lists are not read after the last hop; bit 1: the candidates skip the table pre-read (most edges of
-    // a hop reach nodes that are new to the batch; SPP_DEDUP_PREREAD=1 keeps the pre-read)
-    static const bool dedup_preread = [] {
-      const char* e = getenv("SPP_DEDUP_PREREAD");
-      return e && atoi(e) != 0;
-    }();
+    // a hop reach nodes that are new to the batch; spp_sampler_opts.dedup_preread keeps the pre-read)
+    const bool dedup_preread = s->opt.dedup_preread;
     const int32_t last = ((h == H - 1) ? 1 : 0) | (!dedup_preread ? 2 : 0);
     const int32_t hop_word = h | (s->cb_log2[h] << 8) | (last << 16);
     // positions < pcap_h are inside the per-edge scratch arrays whatever E turns out to be
@@ -2920,18 +3080,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     const unsigned sc_lds = (unsigned)(sizeof(int32_t) * 2 * nbk + (sizeof(uint32_t) + sizeof(uint16_t)) * kScatterTile);
     const int32_t bcap = bucket_cap(pcap_h, nbk);                   // pairs a bucket's region holds
     // the flag pass over the scatter's tiles (k_hop_flag_tiled) wherever the tile kernel runs on the fast path;
-    // SPP_FLAG_TILED=0: position-ordered inv and one random word per position
-    static const bool flag_tiled_on = [] { const char* e = getenv("SPP_FLAG_TILED"); return !e || atoi(e) != 0; }();
-    const bool flag_tiled = flag_tiled_on && !fused && !s->generic[h];
+    // spp_sampler_opts.flag_tiled off: position-ordered inv and one random word per position
+    const bool flag_tiled = pl.flag_tiled;
     if (!fused)
       hipLaunchKernelGGL(k_bucket_scatter, dim3((gsc) * gy), dim3(kTileNT), sc_lds, st, s->d_slots, GG(gsc), h, cb, bcap, region, pcap_h, idmask,
                          flag_tiled ? 1 : 0);
     // LDS table of k_bucket_dedup: 2048 / 4096 / 8192 / 16384 slots (any size works: multiply-shift slot index).
     // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
     // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
-#ifndef SPP_DEDUP_SLOTS12
-#define SPP_DEDUP_SLOTS12 3072  // 24 KB: six workgroups per compute unit, a quarter less to clear per bucket (4096: +3.5 % lone chain)
-#endif
     if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 12)
@@ -2954,11 +3110,10 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     }
     if (!s->generic[h]) {
       // position-ordered staging of the rows' arrays (k_hop_rows_coalesced) while 8 bytes per edge of a workgroup's run fit
-      // 56 KB of LDS (f <= 28); SPP_ROWS_COALESCED=0: the lane-per-row loads
-      static const bool rows_coal = [] { const char* e = getenv("SPP_ROWS_COALESCED"); return !e || atoi(e) != 0; }();
+      // 56 KB of LDS (f <= 28); spp_sampler_opts.rows_coalesced off: the lane-per-row loads
       const int32_t run_cap = (int32_t)(kNT * std::max<int32_t>(1, std::min<int32_t>(f, kFastMaxFanout)));
       for (int rep = 0; rep < dup.rows; ++rep) {
-        if (rows_coal && f >= 1 && f <= 28)
+        if (pl.rows_coal)
           hipLaunchKernelGGL(k_hop_rows_coalesced, dim3((gt) * gy), dim3(kNT), (unsigned)(8 * run_cap), st, s->d_slots, GG(gt), h,
                              idmask, row_idbits, (int32_t)s->tcap[h], pcap_h, run_cap);
         else

@@ -40,7 +40,7 @@
 #include <vector>
 
 #include "exchange_internal.h"
-#include "gather_body.cuh"
+#include "gather_body.hip.h"
 #include "sampler_internal.h"
 
 using namespace spp;

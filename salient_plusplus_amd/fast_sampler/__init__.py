@@ -30,7 +30,7 @@ from .. import _native as nat
 
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
            "multilayer_sample", "full_sample", "to_row_major", "serial_index", "NativeComm", "native_comm",
-           "set_native_comm", "async_errors"]
+           "set_native_comm", "async_errors", "set_sampler_options", "sampler_options", "sampler_info"]
 
 # four slot-sets of 16 batches (~75 MB of workspace per slot at fanout [15,10,5], batch 1024: 4.8 GB).  With two sets, a
 # set's next sampling chain could only start once its previous group was consumed and the consumer waited on chain
@@ -451,6 +451,55 @@ def native_comm(group=None) -> Optional[NativeComm]:
 # sampler pool: workspace outlives Sessions like the reference's global thread pool
 # (fast_sampler.cpp:512-513)
 # --------------------------------------------------------------------------------------------
+_OPT_FIELDS = ("col32", "deg_tags", "row_stubs", "rng_arena", "rng_arena_mb", "fuse_scatter", "flag_tiled",
+               "rows_coalesced", "dedup_preread", "fuse_max_edges", "initial_edge_cap")
+_sampler_opts = {}
+
+
+def set_sampler_options(**kw):
+    """Pin chain variants (include/spp.h spp_sampler_opts) for the samplers created from now on -- Sessions and the free
+    functions alike; pooled samplers are keyed by them.  Switches: 0 = automatic, > 0 on, < 0 off (True / False are
+    accepted); no arguments = everything automatic again.  Every variant produces the same batches."""
+    for k in kw:
+        if k not in _OPT_FIELDS:
+            raise RuntimeError(f"unknown sampler option {k!r} (known: {', '.join(_OPT_FIELDS)})")
+    _sampler_opts.clear()
+    for k, v in kw.items():
+        if isinstance(v, bool):
+            v = 1 if v else -1
+        if int(v) != 0:
+            _sampler_opts[k] = int(v)
+
+
+class sampler_options:
+    """``with sampler_options(row_stubs=False): ...`` -- set_sampler_options for the block."""
+
+    def __init__(self, **kw):
+        self._kw = kw
+
+    def __enter__(self):
+        self._saved = dict(_sampler_opts)
+        set_sampler_options(**self._kw)
+        return self
+
+    def __exit__(self, *exc):
+        _sampler_opts.clear()
+        _sampler_opts.update(self._saved)
+        return False
+
+
+def sampler_info(handle) -> dict:
+    """spp_sampler_get_info as a dict (per-hop lists in processing order, cut to the sampler's hops)."""
+    info = nat.SamplerInfo()
+    nat.check(_lib().spp_sampler_get_info(handle, C.byref(info)))
+    H = int(info.num_hops)
+    out = {}
+    for name, _t in nat.SamplerInfo._fields_:
+        v = getattr(info, name)
+        out[name] = [int(v[h]) for h in range(H)] if hasattr(v, "__len__") else (float(v) if isinstance(v, float) else int(v))
+    return out
+
+
 class _SamplerPool:
     _pool = {}
     _lock = threading.Lock()
@@ -460,8 +509,9 @@ class _SamplerPool:
         """`part`: None or (PartitionCfg, hashable key, tensors to keep alive) -- ownership bucketing
         fused into the sampling chain (distributed Sessions)."""
         gen = _graph_generation(rowptr_d, col_d)
+        opts = tuple(sorted(_sampler_opts.items()))
         key = (rowptr_d.data_ptr(), col_d.data_ptr(), gen, tuple(sizes), device, bool(replace),
-               part[1] if part is not None else None)
+               part[1] if part is not None else None, opts)
         with cls._lock:
             lst = cls._pool.setdefault(key, [])
             for i, (h, mb, ns, keep, _k) in enumerate(lst):
@@ -477,6 +527,8 @@ class _SamplerPool:
         cfg.max_batch, cfg.num_slots, cfg.device = max_batch, slots, device
         cfg.replace = int(bool(replace))
         cfg.graph_generation = gen
+        for k, v in opts:
+            setattr(cfg.opts, k, v)
         if part is not None:
             cfg.part = part[0]
         h = C.c_void_p()
@@ -741,6 +793,10 @@ class Session:
             self._L.spp_session_destroy(self._h)
             self._h = None
         if getattr(self, "_pool_entry", None) is not None:
+            try:
+                self._info = sampler_info(self._pool_entry[0])
+            except Exception:
+                pass
             _SamplerPool.release(self._pool_entry)
             self._pool_entry = None
 
@@ -749,6 +805,13 @@ class Session:
             self.close()
         except Exception:
             pass
+
+    def sampler_info(self) -> dict:
+        """Which chain variants this Session's sampler runs and what its one-off tables cost (spp_sampler_get_info);
+        after the Session has ended: as read when it gave its sampler back."""
+        if getattr(self, "_pool_entry", None) is not None:
+            self._info = sampler_info(self._pool_entry[0])
+        return dict(getattr(self, "_info", None) or {})
 
     def set_export_stream(self, stream):
         """A consumer that delivers every batch on ONE stream says so once: the per-batch path then uses that stream's
@@ -999,7 +1062,7 @@ class Session:
             F = self._x.size(1)
             row_b = F * self._x.element_size()
             # every batch starts on a 16-byte boundary of the arena (rows of 16k + 8 bytes: on an even row), so that the
-            # delivery may store 16-byte pieces whatever the batches before it hold (gather_body.cuh, kVecSpan)
+            # delivery may store 16-byte pieces whatever the batches before it hold (gather_body.hip.h, kVecSpan)
             x_align = 16 // math.gcd(row_b, 16)
             x_split = []
             for U in Us:

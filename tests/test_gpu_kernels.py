@@ -91,7 +91,7 @@ def test_gather_rows_strided_source(lib, row_bytes, stride):
 @pytest.mark.parametrize("n_idx", [1, 2, 63, 64, 65, 255, 1023, 4097, 70001])
 def test_gather_rows_span_form(lib, row_bytes, stride, n_idx):
     """Rows of 16k + 8 bytes out of a 16-byte-strided table take the span form of the row gather (16-byte loads, pieces
-    regrouped across lanes, aligned 16-byte stores: gather_body.cuh kVecSpan) -- the same bytes as the 8-byte form, on whole
+    regrouped across lanes, aligned 16-byte stores: gather_body.hip.h kVecSpan) -- the same bytes as the 8-byte form, on whole
     and partial last iterations, and nothing outside the destination rows.  serial_index, fast_sampler.cpp:238-259."""
     from oracle import oracle as orc
     rng = np.random.default_rng(row_bytes * 131 + n_idx)

@@ -6,7 +6,7 @@
 out=$1; rounds=$2; args=$3; shift 3
 mkdir -p "$(dirname "$out")"
 keep=$(mktemp -d /tmp/abt_keep.XXXXXX)
-cp salient_plusplus_amd/csrc/*.hip salient_plusplus_amd/csrc/*.cuh salient_plusplus_amd/csrc/*.h "$keep"/
+cp salient_plusplus_amd/csrc/*.hip salient_plusplus_amd/csrc/*.h "$keep"/
 restore() { cp "$keep"/* salient_plusplus_amd/csrc/; python3 -m salient_plusplus_amd.build > /dev/null 2>&1; }
 trap restore EXIT
 for r in $(seq 1 $rounds); do
