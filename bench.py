@@ -86,6 +86,13 @@ def parse():
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="launcher only: print the GPU count found without the HIP runtime and whether libamdhip64 is mapped "
                          "into the launcher process, start nothing")
+    ap.add_argument("--hidden", type=int, default=256, help="hidden width of the consumer model (BASELINE configs[4]: 1024)")
+    ap.add_argument("--layers", type=int, default=0,
+                    help="layers of the consumer model (0 = one per hop of the fan-out list, what the MFG can feed: "
+                         "driver/models.py:41-50 consumes one adj per layer)")
+    ap.add_argument("--epochs", type=int, default=4,
+                    help="WHOLE epochs timed wall-clock per leg (iterator creation -> last batch -> synchronize), the first "
+                         "reported separately as the reference does (fast_trainer/train.py:223-316 drops it); 0 = skip")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -228,7 +235,10 @@ def confine_to_cores(n: int) -> list:
     it starts later: torch's, the Session's launcher / exchanger, RCCL's proxies) is confined to the first N cores of its
     affinity mask.  Runs before `import torch`: nothing has touched the GPU yet.  The reference budgets this explicitly
     (utils/exp_driver.py:48-49 num_workers per trainer, driver/parser.py:87-88)."""
-    cores = sorted(os.sched_getaffinity(0))[:max(1, n)]
+    n = max(1, n)
+    r = int(os.environ.get("LOCAL_RANK", "0"))       # every rank its own N cores (wrapping when the mask is short)
+    allc = sorted(os.sched_getaffinity(0))
+    cores = [allc[(r * n + k) % len(allc)] for k in range(min(n, len(allc)))]
     os.sched_setaffinity(0, cores)
     return cores
 
@@ -276,23 +286,15 @@ class TorchSAGE(torch.nn.Module):
         return torch.log_softmax(x, dim=-1)
 
 
-def model_step_timing(feeder, F, n_classes, steps=64, warm=16, windows=6, hip=True, arch="sage", ddp=False):
-    """ms/step of fwd+bwd+Adam with one resident batch re-used, and with the data path feeding it (the
-    training step of fast_trainer/train.py:15-71).  Measured like the data path: `windows` back-to-back
-    windows of `steps` steps after `warm` untimed ones, reported: the MEAN over all windows (their total
-    time / their total steps) with every window kept in the line -- a fresh process pays a few
-    multi-millisecond allocator growths while the model's batch-size-dependent temporaries meet their
-    largest shapes, and one 24-step sample after 4 warm-up steps (round 2) carried them into the figure.
-    hip=True: salient_plusplus_amd.models (HIP message passing); False: the plain-torch formulation
-    above.  ddp=True: the model is wrapped in DistributedDataParallel on the caller's NCCL process group
-    (driver/drivers/ddp.py:349-350), so every backward issues gradient all-reduces between the exchanges.
-    Returns (model_only_ms, with_data_ms, detail)."""
+def make_model_step(F, n_classes, hidden, layers, hip=True, arch="sage", ddp=False):
+    """The training step of fast_trainer/train.py:15-71 (forward, nll_loss, backward, Adam) over one PreparedBatch, as a
+    closure: the SAME model / optimiser serves the windowed legs and the whole-epoch legs."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if hip:
         from salient_plusplus_amd.models import GAT, SAGE
-        model = (GAT if arch == "gat" else SAGE)(F, 256, n_classes, 3).to(dev)
+        model = (GAT if arch == "gat" else SAGE)(F, hidden, n_classes, layers).to(dev)
     else:
-        model = TorchSAGE(F, 256, n_classes).to(dev)
+        model = TorchSAGE(F, hidden, n_classes, layers).to(dev)
     if ddp:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)    # one multi-tensor launch per step
@@ -302,6 +304,60 @@ def model_step_timing(feeder, F, n_classes, steps=64, warm=16, windows=6, hip=Tr
         loss = torch.nn.functional.nll_loss(model(b.x, b.adjs), b.y.reshape(-1))
         loss.backward()
         opt.step()
+    return step
+
+
+def measure_epochs(make_iter, shuffler, get_idx, n_epochs, first_epoch, step=None, distributed=False):
+    """`n_epochs` WHOLE epochs, each timed wall-clock the way the reference times them (fast_trainer/train.py:223-316,
+    driver/drivers/base.py:298-423): seed shuffle -> iterator (Session) creation -> every batch [-> model step] -> the
+    iterator's StopIteration -> synchronize.  Nothing is multiplied: epoch boundaries, Session set-up, ragged last groups
+    and whatever once-per-Session work there is are inside the clock.  The first epoch is kept apart (the reference drops
+    it as warm-up).  N > 1: a barrier on both sides, the slowest rank's time."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    times, nb = [], 0
+    for e in range(n_epochs):
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        shuffler.set_epoch(first_epoch + e)
+        it = make_iter(get_idx())
+        nb, b = 0, None
+        for (b,) in it:
+            if step is not None:
+                step(b)
+            nb += 1
+        torch.cuda.synchronize()
+        if distributed:
+            q = getattr(it, "quiesce", None)
+            if q is not None:
+                q()
+            dist.barrier()
+            torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        del it, b
+    if distributed and times:
+        t = torch.tensor(times, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = [float(v) for v in t.cpu().tolist()]
+    steady = times[1:]
+    return {"epochs": n_epochs, "batches": nb, "first_s": times[0] if times else None,
+            "steady_s_all": [round(v, 5) for v in steady],
+            "steady_s_mean": (sum(steady) / len(steady)) if steady else None,
+            "ms_per_batch_steady": (1e3 * sum(steady) / len(steady) / max(1, nb)) if steady else None,
+            "clock": "perf_counter around shuffle + iterator creation + all batches + synchronize, per epoch"}
+
+
+def model_step_timing(feeder, step, steps=64, warm=16, windows=6):
+    """ms/step of fwd+bwd+Adam with one resident batch re-used, and with the data path feeding it (the
+    training step of fast_trainer/train.py:15-71).  Measured like the data path: `windows` back-to-back
+    windows of `steps` steps after `warm` untimed ones, reported: the MEAN over all windows (their total
+    time / their total steps) with every window kept in the line -- a fresh process pays a few
+    multi-millisecond allocator growths while the model's batch-size-dependent temporaries meet their
+    largest shapes, and one 24-step sample after 4 warm-up steps (round 2) carried them into the figure.
+    `step`: make_model_step's closure.  Returns (model_only_ms, with_data_ms, detail)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
 
     show = os.environ.get("SPP_BENCH_STEP_TIMES") == "1"
 
@@ -804,6 +860,29 @@ def main():
     # exchanges of another, so the Sessions of this leg issue their exchanges from the consumer thread, at the
     # same program point on every rank (SPP_EXCHANGE_ISSUE=consumer).  All ranks take part.
     model_out = None
+    layers = a.layers if a.layers > 0 else len(sizes)
+    n_classes = 47
+    model_name = f"{a.model.upper()} {layers}x{a.hidden}"
+    nb_epoch = (wl.train_idx.numel() // bs) if not distributed else max(1, n_local // bs)
+    # ---- whole epochs, wall-clock (no multiplication): leg (a), the data path alone ----
+    epoch_measured = None
+    next_epoch = [feeder.epoch + 1]
+
+    def run_epochs(mk, step=None):
+        r = measure_epochs(mk, shuffler, get_idx if distributed else shuffler.get_idx, a.epochs, next_epoch[0], step=step,
+                           distributed=distributed)
+        next_epoch[0] += a.epochs
+        return r
+    # which chain variant ran and what its one-off tables cost (read before the timed Session goes away)
+    sess0 = getattr(getattr(feeder.devit, "it", None), "session", None)
+    sinfo = sess0.sampler_info() if sess0 is not None else {}
+    if a.epochs > 0:
+        if distributed:
+            feeder.quiesce()
+        feeder.devit = None                      # the windows' Session ends; its pooled sampler serves the epochs' Sessions
+        gc.collect()
+        _trace("measuring whole epochs (data path alone)")
+        epoch_measured = {"data_path_only": run_epochs(make_iter)}
     if not a.no_model_step:
         try:
             if distributed:
@@ -812,21 +891,30 @@ def main():
                 gc.collect()
                 os.environ["SPP_EXCHANGE_ISSUE"] = "consumer"
                 dist.barrier()
-            m_only, m_data, m_detail = model_step_timing(feeder, F, 47, hip=True, arch=a.model, ddp=distributed)
+            step = make_model_step(F, n_classes, a.hidden, layers, hip=True, arch=a.model, ddp=distributed)
+            m_only, m_data, m_detail = model_step_timing(feeder, step)
             if distributed:
                 feeder.quiesce()
                 t = torch.tensor([m_only, m_data], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)             # the slowest rank's step
                 m_only, m_data = (float(v) for v in t.cpu().tolist())
-            nb_epoch = (wl.train_idx.numel() // bs) if not distributed else max(1, n_local // bs)
             model_out = {"epoch_time_s_with_model_step": nb_epoch * m_data / 1e3,
-                         "model_step": {"model": f"{a.model.upper()} 3x256 (models.py: HIP message passing + library GEMMs, "
-                                                 f"fp32, fused ReLU+dropout, Adam(fused=True))" +
+                         "model_step": {"model": f"{model_name} (models.py: HIP message passing + library GEMMs, "
+                                                 f"fp32, fused ReLU+dropout, Adam(fused=True); one layer per hop of {sizes})" +
                                                  (f", DistributedDataParallel over {world} ranks, exchanges issued by the consumer"
                                                   if distributed else ""),
+                                        "hidden": a.hidden, "layers": layers,
                                         "batches_per_epoch_and_rank": nb_epoch,
                                         "ms_per_step_model_only_resident_batch": m_only,
                                         "ms_per_step_with_data_path": m_data, "timing": m_detail}}
+            if epoch_measured is not None:
+                # leg (b): the default consumer -- x delivered, the model step on every batch
+                if distributed:
+                    feeder.quiesce()
+                feeder.devit = None
+                gc.collect()
+                _trace("measuring whole epochs (with the model step)")
+                epoch_measured["with_model_step"] = run_epochs(make_iter, step)
             if not distributed and a.model == "sage" and not a.no_fused_leg:
                 # Row g1: the opt-in fused consumer.  The Session delivers MFG + labels + n_id and NO feature rows
                 # (PreparedBatch.x = TableRows(resident table, n_id)); models.SAGE's first layer aggregates straight from
@@ -840,7 +928,8 @@ def main():
                     fused_sampler.idx = idx
                     return DevicePrefetcher([dev], iter(fused_sampler))
                 fused_feeder = EpochFeeder(make_fused_iter, shuffler, shuffler.get_idx)
-                f_only, f_data, f_detail = model_step_timing(fused_feeder, F, 47, hip=True, arch=a.model)
+                fused_step = make_model_step(F, n_classes, a.hidden, layers, hip=True, arch=a.model)
+                f_only, f_data, f_detail = model_step_timing(fused_feeder, fused_step)
                 fused_feeder.devit = None
                 gc.collect()
                 model_out["model_step"]["fused_first_layer"] = {
@@ -850,14 +939,32 @@ def main():
                     "data_path_cost_ms": f_data - f_only, "epoch_time_s_with_model_step": nb_epoch * f_data / 1e3,
                     "timing": f_detail}
                 model_out["model_step"]["data_path_cost_ms"] = m_data - m_only
+                if epoch_measured is not None:
+                    _trace("measuring whole epochs (fused consumer)")
+                    epoch_measured["with_model_step_fused_first_layer"] = run_epochs(make_fused_iter, fused_step)
+                    gc.collect()
+                del fused_step
             if not distributed:
-                t_only, t_data, _ = model_step_timing(feeder, F, 47, hip=False, windows=2, warm=4)
+                t_step = make_model_step(F, n_classes, a.hidden, layers, hip=False)
+                t_only, t_data, _ = model_step_timing(feeder, t_step, windows=2, warm=4)
                 model_out["model_step"]["plain_torch_formulation"] = {
                     "ms_per_step_model_only_resident_batch": t_only, "ms_per_step_with_data_path": t_data}
         except Exception as e:  # noqa: BLE001
             if distributed:
                 raise                                 # a rank that fell out of a collective sequence: fail loudly
             model_out = {"model_step": {"error": repr(e)}}
+    if epoch_measured is not None:
+        # measured against extrapolated (batches x ms/step of the windows), per leg
+        ext = {"data_path_only": nb_epoch * (dt / a.steps)}
+        if model_out is not None and "epoch_time_s_with_model_step" in model_out:
+            ext["with_model_step"] = model_out["epoch_time_s_with_model_step"]
+            fl = model_out["model_step"].get("fused_first_layer")
+            if fl:
+                ext["with_model_step_fused_first_layer"] = fl["epoch_time_s_with_model_step"]
+        for k_, v_ in epoch_measured.items():
+            if k_ in ext and v_.get("steady_s_mean"):
+                v_["extrapolated_s"] = ext[k_]
+                v_["measured_over_extrapolated"] = v_["steady_s_mean"] / ext[k_]
 
     from salient_plusplus_amd.synthetic import LOCALITY
     locality_note = ""
@@ -951,7 +1058,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
                                    f"fanout {sizes}, batch {bs}, all features in HBM",
-                       "parallelism": parallelism, "slots_in_flight": a.slots},
+                       "parallelism": parallelism, "slots_in_flight": a.slots,
+                       # which form of the sampling chain the library chose by itself (spp_sampler_get_info)
+                       "sampler_variant": {k_: sinfo.get(k_) for k_ in ("col32", "deg_tags", "row_stubs", "rng_arena", "idbits", "tag_cap",
+                                                                        "generic", "fused_pick", "flag_tiled", "rows_coalesced",
+                                                                        "bucket_log2", "dedup_table_slots")} if sinfo else None},
             "windows": {"n": R, "steps_each": a.steps, "reported": "mean over all windows (timed_region_s / all steps)",
                         "ms_per_step_min": min(window_ms), "ms_per_step_median": dt_median / a.steps * 1e3,
                         "ms_per_step_mean": dt_mean / a.steps * 1e3,
@@ -975,9 +1086,21 @@ def main():
                     "torch_device_allocs_in_timed_region": dev_allocs_timed},   # hipMalloc calls of the caching allocator
             "priming_steps": max(0, a.prime),
             "batches_per_s": a.steps * world / dt,
+            # (an EXTRAPOLATION: batches x ms/step of the windows; the measured epochs are under "epoch_measured")
             "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
             "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),
             "graph_build_s": t_build,
+            # once-per-process work the timed windows lean on and never pay: the int32 neighbour array, the row stubs (both
+            # once per graph) and the mt19937 streams of the whole epoch (once per range table; the pooled sampler keeps
+            # them across epochs).  The measured epochs' FIRST epoch is where a training run would see them.
+            "setup": {"col32_ms": sinfo.get("col32_ms"), "col32_GB": (sinfo.get("col32_bytes") or 0) / 1e9,
+                      "row_stubs_ms": sinfo.get("row_stubs_ms"), "row_stubs_GB": (sinfo.get("row_stubs_bytes") or 0) / 1e9,
+                      "rng_arena_ms": sinfo.get("rng_arena_ms"), "rng_arena_GB": (sinfo.get("rng_arena_bytes") or 0) / 1e9,
+                      "rng_arena_batches": sinfo.get("rng_arena_batches"),
+                      "rng_arena_ms_per_batch_amortised_over_one_epoch":
+                          (sinfo.get("rng_arena_ms") or 0.0) / max(1, sinfo.get("rng_arena_batches") or 1),
+                      "charged_to": "neither `value` nor the windows: set-up (first Session of the process)"} if sinfo else None,
+            "epoch_measured": epoch_measured,
             "roofline": roof,
             "roofline_sampler": roof_s,
         }

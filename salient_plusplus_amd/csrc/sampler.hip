@@ -3187,7 +3187,10 @@ static spp_status fill_deliver_args(spp_sampler* s, int slot, const spp_mfg_out*
     total += len;
     ++n;
   };
-  if (mfg) {
+  // Measurement aid (WRONG RESULTS: the MFG tensors stay unwritten): SPP_WHATIF_NO_WIDEN=1 drops the int32 -> int64
+  // widening from the delivery launch, which bounds what writing the final arrays from the chain could gain.
+  static const bool whatif_no_widen = [] { const char* e = getenv("SPP_WHATIF_NO_WIDEN"); return e && atoi(e) != 0; }();
+  if (mfg && !whatif_no_widen) {
     add(sl.p.n_ids, mfg->n_id, U);
     for (int k = 0; k < H; ++k) {
       const int h = H - 1 - k;

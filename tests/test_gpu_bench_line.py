@@ -65,9 +65,30 @@ def _check_common(d, n_gpus):
     assert rs["algorithmic_bytes_per_batch"] >= 16 * d["sampled_edges_per_batch"]
 
 
+def _check_epochs(d, legs):
+    """whole epochs timed wall-clock (not batches x ms/step), the first one apart; beside them the extrapolation they replace"""
+    em = d["epoch_measured"]
+    for leg in legs:
+        e = em[leg]
+        assert e["epochs"] == 4 and e["batches"] >= 1 and e["first_s"] > 0 and len(e["steady_s_all"]) == 3
+        assert all(v > 0 for v in e["steady_s_all"])
+        assert abs(e["steady_s_mean"] - sum(e["steady_s_all"]) / 3) < 1e-4
+        assert e["extrapolated_s"] > 0 and abs(e["measured_over_extrapolated"] - e["steady_s_mean"] / e["extrapolated_s"]) < 1e-3
+    # the once-per-process work the windows never pay, and which chain variant the library chose by itself
+    st = d["setup"]
+    for k in ("col32_ms", "row_stubs_ms", "rng_arena_ms", "col32_GB", "row_stubs_GB", "rng_arena_GB", "rng_arena_batches"):
+        assert k in st, k
+    assert st["col32_GB"] > 0 and st["rng_arena_GB"] > 0 and st["rng_arena_ms"] > 0
+    v = d["config"]["sampler_variant"]
+    assert v["col32"] == 1 and v["row_stubs"] == 1 and v["deg_tags"] == 1 and v["rng_arena"] == 1
+    assert v["fused_pick"] == [1, 1, 0] and v["flag_tiled"] == [0, 0, 1] and v["rows_coalesced"] == [1, 1, 1]
+
+
 def test_single_gpu_line():
     d = _run([])
     _check_common(d, 1)
+    _check_epochs(d, ["data_path_only", "with_model_step", "with_model_step_fused_first_layer"])
+    assert d["model_step"]["hidden"] == 256 and d["model_step"]["layers"] == 3
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     m = d["model_step"]
@@ -87,3 +108,12 @@ def test_partitioned_path_line_with_the_ddp_leg():
     assert "DistributedDataParallel" in m["model"] and m["ms_per_step_with_data_path"] > 0
     ex = d.get("exchange")
     assert ex is not None and ex.get("rccl_world") == 1
+    _check_epochs(d, ["data_path_only", "with_model_step"])
+
+
+def test_model_shape_flags():
+    """--hidden / --layers: BASELINE configs[4] names a 1024-wide SAGE over a two-hop fan-out"""
+    d = _run(["--hidden", "1024", "--fanouts", "25,15", "--no-cpu-baseline", "--no-fused-leg", "--epochs", "0"])
+    m = d["model_step"]
+    assert m["hidden"] == 1024 and m["layers"] == 2 and "SAGE 2x1024" in m["model"] and m["ms_per_step_with_data_path"] > 0
+    assert d["epoch_measured"] is None

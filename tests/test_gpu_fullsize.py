@@ -62,7 +62,10 @@ def test_fullsize_epoch_properties(products):
     _epoch_properties(products, 48)
 
 
-def _epoch_properties(wl, nb):
+def _epoch_properties(wl, nb, digests=None, info_out=None):
+    """digests: a list that receives one checksum tuple per batch (sizes, position-weighted sums of every rowptr / col, the
+    feature rows' bit sum) -- equal digests of two runs = the same batches; info_out: a dict that receives
+    Session.sampler_info() (which chain variant ran)."""
     from salient_plusplus_amd import fast_sampler as fs
     idx = wl.train_idx[:nb * wl.batch_size].contiguous()
     deg = (wl.rowptr[1:] - wl.rowptr[:-1])
@@ -101,7 +104,15 @@ def _epoch_properties(wl, nb):
                     same = row_of[1:] == row_of[:-1]
                     assert bool((cl[1:][same] >= cl[:-1][same]).all())
             assert adjs[-1][3][0] == wl.batch_size
+            if digests is not None:
+                d = [U, int(x.view(torch.int16).sum(dtype=torch.int64))]
+                for (rp, cl, _e, (T, S)) in adjs:
+                    w = torch.arange(cl.numel(), device=cl.device) % 1009 + 1
+                    d += [T, S, int(rp.sum()), int((cl * w).sum())]
+                digests.append(tuple(d))
             seen += 1
+        if info_out is not None:
+            info_out.update(s.sampler_info())
     finally:
         s.close()
     assert seen == nb
@@ -162,7 +173,35 @@ def test_mag_fullsize_epoch_properties():
     torch.cuda.synchronize()
     try:
         assert wl.x.shape == (121_751_666, 768) and wl.fanouts == [25, 15]
-        _epoch_properties(wl, 24)
+        # Which chain variant the library picks here is decided by the free HBM (128 B x N of row stubs against a quarter of
+        # what is free after the 187 GB of features: a knife edge) -- so the run records what it picked, and BOTH sides of
+        # every such rule run at full size and must deliver the same batches (digest per batch).  The variants' own
+        # oracle parity is tests/test_gpu_sampler_variants.py.
+        auto_d, auto_info = [], {}
+        _epoch_properties(wl, 24, auto_d, auto_info)
+        for k in ("row_stubs", "deg_tags", "col32", "rng_arena", "fused_pick", "flag_tiled", "rows_coalesced"):
+            assert k in auto_info, k
+        assert auto_info["col32"] == 1 and auto_info["rng_arena"] in (0, 1)
+        print("S-mag sampler variant chosen automatically:", auto_info)
+        try:
+            import json
+            import os
+            out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            json.dump(auto_info, open(os.path.join(out, "mag_sampler_variant.json"), "w"))
+        except OSError:
+            pass
+        others = [dict(row_stubs=not auto_info["row_stubs"]), dict(rng_arena=not auto_info["rng_arena"]),
+                  dict(row_stubs=False, rng_arena=False)]
+        for opts in others:
+            fs.clear_resident_cache()                           # the previous variant's sampler and tables go first
+            torch.cuda.empty_cache()
+            with fs.sampler_options(**opts):
+                d, info = [], {}
+                _epoch_properties(wl, 24, d, info)
+            for k, v in opts.items():
+                assert info[k] == int(v), (opts, info)
+            assert d == auto_d, f"variant {opts} delivered other batches than the automatic one"
     finally:
         del wl
         fs.clear_resident_cache()
