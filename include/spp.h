@@ -230,6 +230,17 @@ typedef struct spp_mfg_out {
                                      MFG order inside a group (fast_sampler.cpp:1063-1068)        */
   int64_t* cached;                /* int64[part_counts[P]]: cache rows of the hits (:1256)         */
   int64_t* perm;                  /* int64[U]: perm_partition_to_mfg (:1085, :1246-1252)           */
+  /* Row references (opt-in; spp_session_export / spp_session_export_group with x_out_dev == NULL): instead of
+   * writing the batch's feature matrix the delivery writes WHERE every row lives, for a consumer whose first layer
+   * reads the rows exactly once (spp_sage_operand_forward_rows) -- x = cat(...)[perm] (transferers.py:472-486) is
+   * neither written nor read back.  row_addr[j] = device address of the feature row of MFG node j: in the local
+   * partition (or the one resident table of a single-GPU session), in the VIP cache, in a peer's partition (P2P
+   * transport), or -- RCCL transport -- in x_remote, into which the rows received for THIS batch are copied (dense
+   * rows, peer-major, request order: U - part_counts[rank] - part_counts[P] of them); the group's receive buffer is
+   * free again when the launch completes, so nothing outlives the delivery but caller-owned memory and the
+   * resident tables. */
+  int64_t* row_addr;              /* int64[U], or NULL                                             */
+  void* x_remote;                 /* [remote rows, row_bytes] dense, or NULL (nothing remote / P2P) */
 } spp_mfg_out;
 
 /* rowptr_dev / col_dev must stay valid AND unchanged for the sampler's lifetime: an int32 copy of the
@@ -483,6 +494,15 @@ typedef struct spp_exchange_cfg {
   int64_t cache_rows;
   int64_t x_local_stride_bytes;    /* distance between rows of x_local / of the cache (0 = dense)    */
   int64_t cache_stride_bytes;
+  /* P2P transport (opt-in; SURVEY 8(e) "direct P2P loads of peer HBM inside the gather kernel"): peer_x_dev != NULL
+   * names, for every rank m, the base address IN THIS PROCESS of rank m's partition (its x_local: same row_bytes and
+   * stride; peer_x_dev[rank] is ignored) -- plain device pointers when the ranks share a process, otherwise
+   * mappings opened with spp_ipc_open from handles the owners exported (spp_ipc_export).  The delivery then reads a
+   * remote row straight out of its owner's HBM over xGMI: no id exchange, no serve gather, no send / receive
+   * buffers, no host read per group, and `comm` may be NULL.  The partitions must stay allocated and unchanged while
+   * any peer's Session runs. */
+  const void* const* peer_x_dev;   /* host array [num_parts], or NULL = exchange over `comm`         */
+  int64_t peer_x_stride_bytes;     /* distance between rows of every peer's table (0 = x_local's)    */
   int32_t issue_on_consumer;       /* 0: a session thread issues each group's exchange as soon as its
                                       sampling completes (most overlap).  1: spp_session_next issues it,
                                       at the same point of the program on every rank (own group when
@@ -491,6 +511,15 @@ typedef struct spp_exchange_cfg {
                                       all-reduces: both communicators' kernels are then queued in the
                                       same order on every rank.                                      */
 } spp_exchange_cfg;
+
+/* Cross-process mapping of a device allocation (hipIpcGetMemHandle / hipIpcOpenMemHandle), for the P2P transport:
+ * the owner exports the allocation that CONTAINS ptr_dev (handle_out: SPP_IPC_HANDLE_BYTES bytes; *offset_out = ptr_dev's
+ * offset inside it), ships both out of band (e.g. torch.distributed all_gather_object), and a peer process on the same
+ * node opens the handle and adds the offset.  spp_ipc_close unmaps what spp_ipc_open returned. */
+#define SPP_IPC_HANDLE_BYTES 64
+spp_status spp_ipc_export(const void* ptr_dev, void* handle_out, int64_t* offset_out);
+spp_status spp_ipc_open(const void* handle, int32_t device, void** base_out);
+spp_status spp_ipc_close(void* base);
 
 /* BLOCKING: returns when the session's threads have issued everything they can without further
  * consumption (sampling chains and exchanges of the slot-sets in flight) and that work has completed
@@ -547,6 +576,15 @@ spp_status spp_sage_operand_forward_table(const int64_t* rowptr_dev, const int64
                                           const void* table_dev, int32_t table_is_half, int64_t table_stride_elems,
                                           int64_t table_rows, const int64_t* n_id_dev, int64_t F, float* out_dev,
                                           int64_t out_stride_elems /* >= 2F */, void* stream);
+/* The same operand from ROW REFERENCES (spp_mfg_out.row_addr): row j of the batch is the F elements at device
+ * address row_addr_dev[j] (fp16 or fp32; 8-byte aligned fp16 / 16-byte aligned fp32 rows when F % 4 == 0).  Same rows,
+ * same summation order as spp_sage_operand_forward over the assembled x: the operand is bit-identical. */
+spp_status spp_sage_operand_forward_rows(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                         const int64_t* row_addr_dev, int32_t rows_are_half, int64_t F, float* out_dev,
+                                         int64_t out_stride_elems /* >= 2F */, void* stream);
+/* dst[j,:] = the row_bytes bytes at row_addr_dev[j], j < n: the feature matrix itself out of row references
+ * (what any consumer other than the fused first layer reads: RowRefs.materialize()). */
+spp_status spp_gather_row_refs(const int64_t* row_addr_dev, int64_t n, int64_t row_bytes, void* dst_dev, void* stream);
 /* Its backward: grad_x [S, F] is written completely -- rows < T start from the gradient of the x_target
  * half, the others from zero, then the mean's gradient is scattered on top (fp32 atomics). */
 spp_status spp_sage_operand_backward(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
