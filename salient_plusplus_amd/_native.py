@@ -54,7 +54,7 @@ class MfgCounts(C.Structure):
 
 class MfgOut(C.Structure):
     _fields_ = [("n_id", p), ("rowptr", p * SPP_MAX_HOPS), ("col", p * SPP_MAX_HOPS),
-                ("parts", p), ("cached", p), ("perm", p)]
+                ("parts", p), ("cached", p), ("perm", p), ("row_addr", p), ("x_remote", p)]
 
 
 class GroupOut(C.Structure):
@@ -64,7 +64,8 @@ class GroupOut(C.Structure):
 class ExchangeCfg(C.Structure):
     _fields_ = [("comm", p), ("x_local_dev", p), ("x_local_rows", i64), ("row_bytes", i64),
                 ("cache_feats_dev", p), ("cache_rows", i64), ("x_local_stride_bytes", i64),
-                ("cache_stride_bytes", i64), ("issue_on_consumer", i32)]
+                ("cache_stride_bytes", i64), ("peer_x_dev", C.POINTER(p)), ("peer_x_stride_bytes", i64),
+                ("issue_on_consumer", i32)]
 
 
 class SessionCfg(C.Structure):
@@ -154,11 +155,17 @@ SIGNATURES = {
     "spp_gat_aggregate_backward_gather_workspace_bytes": (i64, [i64, i64, i64]),
     "spp_gat_aggregate_backward_gather": (C.c_int, [p, p, i64, i64, i64, p, i32, i64, i64, p, p, C.c_float, p, p, p, p,
                                                     p, p, p, p, p, p, i64, p]),
+    "spp_sage_operand_forward_rows": (C.c_int, [p, p, i64, p, i32, i64, p, i64, p]),
+    "spp_gather_row_refs": (C.c_int, [p, i64, i64, p, p]),
+    "spp_ipc_export": (C.c_int, [p, p, C.POINTER(i64)]),
+    "spp_ipc_open": (C.c_int, [p, i32, C.POINTER(p)]),
+    "spp_ipc_close": (C.c_int, [p]),
     "spp_session_try_next": (C.c_int, [p, C.POINTER(BatchDesc)]),
     "spp_session_quiesce": (C.c_int, [p]),
     "spp_session_exchange_stats": (C.c_int, [p, C.POINTER(i64), C.POINTER(i64)]),
 }
 SPP_COMM_ID_BYTES = 128
+SPP_IPC_HANDLE_BYTES = 64
 
 _lib = None
 

@@ -69,7 +69,9 @@ __device__ __forceinline__ f4 relu_dropout4(f4 v, int64_t i4, const ActArgs& a) 
 // n_id, int64) -- the batch's feature matrix is never written and re-read (242 MB each way at papers scale); the sum
 // runs over the same rows in the same order as over a materialised x[n_id], so the operand is bit-identical.  An id
 // outside [0, x_rows) reads row 0 (no fault).
-template <typename Tin, bool VEC4, bool kAct = false, bool kTable = false>
+// kRefs (first layer, opt-in, partitioned path): row j of the batch is the F elements at ADDRESS nid[j] (row references,
+// spp_mfg_out.row_addr: local partition / VIP cache / received rows / a peer's partition); x and x_stride are unused.
+template <typename Tin, bool VEC4, bool kAct = false, bool kTable = false, bool kRefs = false>
 __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restrict__ rowptr,
                                                          const int64_t* __restrict__ col, int64_t T,
                                                          const Tin* __restrict__ x, int64_t x_stride, int64_t F,
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
   const int64_t b = rowptr[t], e = rowptr[t + 1];
   const float inv = 1.0f / (float)(e > b ? e - b : 1);
   auto row4 = [&](int64_t j, int64_t c) {  // four columns of row j (activated on load with kAct)
+    if constexpr (kRefs) return load4(reinterpret_cast<const Tin*>((uintptr_t)nid[j]) + c);
     if constexpr (kTable) {
       const int64_t g = nid[j];
       j = (uint64_t)g < (uint64_t)x_rows ? g : 0;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(kAggNT) void k_csr_mean_fwd(const int64_t* __restri
       float acc = 0.f;
       for (int64_t k = b; k < e; ++k) acc += load1(x + row_of(col[k]) * x_stride + c);
       out[t * out_stride + c] = acc * inv;
+      static_assert(!kRefs || VEC4, "row references use the vector form");
     }
   }
 }
@@ -361,6 +365,30 @@ static spp_status mean_forward(const int64_t* rowptr_dev, const int64_t* col_dev
     if (vec) SPP_AGG(float, true); else SPP_AGG(float, false);
   }
 #undef SPP_AGG
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
+}
+
+extern "C" spp_status spp_sage_operand_forward_rows(const int64_t* rowptr_dev, const int64_t* col_dev, int64_t num_targets,
+                                                    const int64_t* row_addr_dev, int32_t rows_are_half, int64_t F,
+                                                    float* out_dev, int64_t out_stride_elems, void* stream) {
+  SPP_REQUIRE(num_targets >= 0 && F >= 0, "spp_sage_operand_forward_rows: negative size");
+  if (num_targets == 0 || F == 0) return SPP_OK;
+  SPP_REQUIRE(rowptr_dev && out_dev && row_addr_dev, "spp_sage_operand_forward_rows: NULL buffer");
+  SPP_REQUIRE(out_stride_elems >= 2 * F, "spp_sage_operand_forward_rows: the operand [mean | x_target] needs 2F columns");
+  SPP_REQUIRE(F % 4 == 0 && (reinterpret_cast<uintptr_t>(out_dev) % 16 == 0) && (out_stride_elems % 4 == 0),
+              "spp_sage_operand_forward_rows: needs F %% 4 == 0 and a 16-byte aligned operand (F = %lld)", (long long)F);
+  hipStream_t st = as_stream(stream);
+  const int lpr_log2 = lanes_log2(F / 4);
+  const unsigned grid = (unsigned)ceil_div(num_targets << lpr_log2, kAggNT);
+  if (rows_are_half)
+    hipLaunchKernelGGL((k_csr_mean_fwd<__half, true, false, false, true>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev,
+                       num_targets, static_cast<const __half*>(nullptr), (int64_t)0, F, lpr_log2, out_dev, out_stride_elems, 1,
+                       ActArgs{}, row_addr_dev, (int64_t)0);
+  else
+    hipLaunchKernelGGL((k_csr_mean_fwd<float, true, false, false, true>), dim3(grid), dim3(kAggNT), 0, st, rowptr_dev, col_dev,
+                       num_targets, static_cast<const float*>(nullptr), (int64_t)0, F, lpr_log2, out_dev, out_stride_elems, 1,
+                       ActArgs{}, row_addr_dev, (int64_t)0);
   SPP_HIP_TRY(hipGetLastError());
   return SPP_OK;
 }

@@ -187,6 +187,36 @@ spp_status spp_profile_read(int kind, double* total_ms, int64_t* launches, int64
   return SPP_OK;
 }
 
+// ---- cross-process mappings for the P2P transport (include/spp.h) ----
+spp_status spp_ipc_export(const void* ptr_dev, void* handle_out, int64_t* offset_out) {
+  static_assert(sizeof(hipIpcMemHandle_t) <= SPP_IPC_HANDLE_BYTES, "SPP_IPC_HANDLE_BYTES too small");
+  SPP_REQUIRE(ptr_dev && handle_out && offset_out, "spp_ipc_export: NULL argument");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  SPP_HIP_TRY(hipMemGetAddressRange(&base, &size, const_cast<void*>(ptr_dev)));
+  hipIpcMemHandle_t h;
+  SPP_HIP_TRY(hipIpcGetMemHandle(&h, base));
+  memset(handle_out, 0, SPP_IPC_HANDLE_BYTES);
+  memcpy(handle_out, &h, sizeof(h));
+  *offset_out = (int64_t)(static_cast<const char*>(ptr_dev) - static_cast<const char*>(base));
+  return SPP_OK;
+}
+
+spp_status spp_ipc_open(const void* handle, int32_t device, void** base_out) {
+  SPP_REQUIRE(handle && base_out, "spp_ipc_open: NULL argument");
+  SPP_HIP_TRY(hipSetDevice(device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  SPP_HIP_TRY(hipIpcOpenMemHandle(base_out, h, hipIpcMemLazyEnablePeerAccess));
+  return SPP_OK;
+}
+
+spp_status spp_ipc_close(void* base) {
+  if (!base) return SPP_OK;
+  SPP_HIP_TRY(hipIpcCloseMemHandle(base));
+  return SPP_OK;
+}
+
 // gen.seed(pair.second * 17 + 5)  (reference fast_sampler.cpp:994; pair.second is int32)
 uint32_t spp_batch_seed(int32_t stop) { return (uint32_t)(stop * 17 + 5); }
 

@@ -55,6 +55,16 @@ static spp_status launch_gather(const void* src, int64_t src_rows, int64_t row_b
   return SPP_OK;
 }
 
+// dst[j,:] = the row at address addr[j] (row references, spp_mfg_out.row_addr)
+template <int VEC>
+__global__ __launch_bounds__(kGatherThreads) void k_gather_row_refs(const int64_t* __restrict__ addr, int64_t n,
+                                                                     int64_t row_bytes, int chunks, int lpr_log2,
+                                                                     char* __restrict__ dst) {
+  move_rows_body<VEC, false>([=](int64_t r) { return addr[r]; },
+                             [=](int64_t a) { return reinterpret_cast<const char*>((uintptr_t)a); }, n, row_bytes, chunks,
+                             lpr_log2, dst, blockIdx.x, gridDim.x);
+}
+
 // used by sampler.hip (int32 node list of a slot)
 spp_status gather_rows_i32(const void* src, int64_t src_rows, int64_t row_bytes, int64_t src_stride,
                            const int32_t* idx, int64_t n, void* dst, hipStream_t st) {
@@ -107,6 +117,31 @@ extern "C" spp_status spp_gather_rows_strided(const void* src_dev, int64_t src_r
                                        static_cast<const int64_t*>(idx_dev), n, dst_dev, spp::as_stream(stream));
   return spp::launch_gather<int32_t>(src_dev, src_rows, row_bytes, src_stride_bytes,
                                      static_cast<const int32_t*>(idx_dev), n, dst_dev, spp::as_stream(stream));
+}
+
+extern "C" spp_status spp_gather_row_refs(const int64_t* row_addr_dev, int64_t n, int64_t row_bytes, void* dst_dev,
+                                          void* stream) {
+  SPP_REQUIRE(n >= 0 && row_bytes >= 0, "spp_gather_row_refs: negative size");
+  if (n == 0 || row_bytes == 0) return SPP_OK;
+  SPP_REQUIRE(row_addr_dev && dst_dev, "spp_gather_row_refs: NULL buffer");
+  // every referenced row is aligned to the largest power of two (<= 16) that divides row_bytes: rows of a table whose
+  // stride is a multiple of it, dense rows of x_remote
+  const spp::GatherGeom gg = spp::gather_geometry(nullptr, dst_dev, row_bytes, n, 0, /*allow_span=*/false);
+  hipStream_t st = spp::as_stream(stream);
+  char* d = static_cast<char*>(dst_dev);
+#define SPP_LAUNCH_REFS(V)                                                                                       \
+  hipLaunchKernelGGL(spp::k_gather_row_refs<V>, dim3((unsigned)gg.grid), dim3(spp::kGatherThreads), 0, st, row_addr_dev, n, \
+                     row_bytes, gg.chunks, gg.lpr_log2, d)
+  switch (gg.vec) {
+    case 16: SPP_LAUNCH_REFS(16); break;
+    case 8: SPP_LAUNCH_REFS(8); break;
+    case 4: SPP_LAUNCH_REFS(4); break;
+    case 2: SPP_LAUNCH_REFS(2); break;
+    default: SPP_LAUNCH_REFS(1); break;
+  }
+#undef SPP_LAUNCH_REFS
+  SPP_HIP_TRY(hipGetLastError());
+  return SPP_OK;
 }
 
 extern "C" spp_status spp_to_row_major(const void* src_dev, int64_t rows, int64_t cols, int elem_bytes, void* dst_dev,

@@ -2028,7 +2028,16 @@ struct DeliverArgs {
   const char* cache;
   int64_t cache_stride;
   const int2* psrc;
+  // RCCL transport: row of `recv` where peer m's rows for this batch start.  P2P transport (p2p != 0): the ADDRESS of
+  // node 0's row in peer m's partition (base - offsets[m] * stride), so that a remote row is src_base[m] + nid * p2p_stride
   int64_t recv_base[SPP_MAX_PARTS];
+  int32_t p2p, nb_a, nb_r, pad2;
+  int64_t p2p_stride;
+  // row references (spp_mfg_out.row_addr): workgroups [nb_x, nb_x + nb_a) write every row's address instead of moving it
+  // (nb_x == 0 then), [.., + nb_r) copy the rows received for this batch into xr_dst (segment m: xr_cnt[m] rows)
+  int64_t* addr_out;
+  char* xr_dst;
+  int32_t xr_cnt[SPP_MAX_PARTS];
 };
 
 // The same for a whole GROUP of batches in ONE launch (spp_session_export_group).  A launch per batch left the
@@ -2040,8 +2049,71 @@ struct GroupBlocks {
   int32_t start[kMaxGroup + 1];
 };
 
-template <int VEC>
+// where the feature row of MFG node r lives (the source the assembly would read)
+__device__ __forceinline__ const char* deliver_row_address(const DeliverArgs& a, int64_t r, const int64_t* xr_off) {
+  const int64_t nid = a.n_ids[r];
+  if (!a.asm_on) return a.x_src + nid * a.x_src_stride;
+  const int2 c = a.psrc[r];
+  if (c.x == a.rank) return a.x_src + (int64_t)c.y * a.x_src_stride;
+  if (c.x == a.P) return a.cache + (int64_t)c.y * a.cache_stride;
+  if (a.p2p) return reinterpret_cast<const char*>(a.recv_base[c.x]) + nid * a.p2p_stride;
+  return a.xr_dst + (xr_off[c.x] + c.y) * a.x_row_bytes;   // its copy in x_remote (segment-wise, below)
+}
+
+template <int VEC, bool kP2P>
 __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
+  if (b >= a.nb_x && b < a.nb_x + a.nb_a) {
+    // row references: one address per row, four rows per thread and round (psrc / n_ids loads of a round in flight together)
+    __shared__ int64_t xr_off[SPP_MAX_PARTS + 1];
+    if (threadIdx.x == 0) {
+      int64_t acc = 0;
+      for (int m = 0; m < a.P; ++m) {
+        xr_off[m] = acc;
+        acc += a.xr_cnt[m];
+      }
+    }
+    __syncthreads();
+    const int64_t nthreads = (int64_t)a.nb_a * kNT;
+    for (int64_t r0 = (int64_t)(b - a.nb_x) * kNT + threadIdx.x; r0 < a.x_rows; r0 += 4 * nthreads) {
+      const char* p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * nthreads;
+        p[u] = deliver_row_address(a, r < a.x_rows ? r : a.x_rows - 1, xr_off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + u * nthreads;
+        if (r < a.x_rows) a.addr_out[r] = (int64_t)reinterpret_cast<uintptr_t>(p[u]);
+      }
+    }
+    return;
+  }
+  if (b >= a.nb_x + a.nb_a && b < a.nb_x + a.nb_a + a.nb_r) {
+    // the rows received for this batch, peer after peer: contiguous in the group's receive buffer, contiguous in x_remote
+    const int64_t vb = b - a.nb_x - a.nb_a;
+    int64_t done = 0;
+    for (int m = 0; m < a.P; ++m) {
+      const int64_t bytes = (int64_t)a.xr_cnt[m] * a.x_row_bytes;
+      if (bytes == 0) continue;
+      const char* src = a.recv + a.recv_base[m] * a.x_row_bytes;
+      char* dst = a.xr_dst + done;
+      done += bytes;
+      if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 15) == 0) {
+        const int64_t n16 = bytes >> 4;
+        for (int64_t k = vb * kNT + threadIdx.x; k < n16; k += (int64_t)a.nb_r * kNT)
+          row_store(reinterpret_cast<const u32x4*>(src)[k], reinterpret_cast<u32x4*>(dst) + k);
+      } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | (uintptr_t)bytes) & 3) == 0) {
+        const int64_t n4 = bytes >> 2;
+        for (int64_t k = vb * kNT + threadIdx.x; k < n4; k += (int64_t)a.nb_r * kNT)
+          reinterpret_cast<uint32_t*>(dst)[k] = reinterpret_cast<const uint32_t*>(src)[k];
+      } else {
+        for (int64_t k = vb * kNT + threadIdx.x; k < bytes; k += (int64_t)a.nb_r * kNT) dst[k] = src[k];
+      }
+    }
+    return;
+  }
+  if (b >= a.nb_x) b -= a.nb_a + a.nb_r;
   if (b < a.nb_x) {
     if (!a.asm_on) {
 #ifndef SPP_DELIVER_NT
@@ -2049,6 +2121,17 @@ __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
 #endif
       gather_rows_body<VEC, int32_t, SPP_DELIVER_NT>(a.x_src, a.n_ids, a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b,
                                      a.nb_x, a.x_src_stride);
+    } else if constexpr (kP2P) {
+      // P2P transport: a remote row is read in its owner's partition (xGMI), at row (node id - offsets[m])
+      struct Key { int2 c; int32_t nid; };
+      move_rows_body<VEC, false>(
+          [&](int64_t r) { return Key{a.psrc[r], a.n_ids[r]}; },
+          [&](Key k) -> const char* {
+            if (k.c.x == a.rank) return a.x_src + (int64_t)k.c.y * a.x_src_stride;
+            if (k.c.x == a.P) return a.cache + (int64_t)k.c.y * a.cache_stride;
+            return reinterpret_cast<const char*>(a.recv_base[k.c.x]) + (int64_t)k.nid * a.p2p_stride;
+          },
+          a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b, a.nb_x);
     } else {
       // combine (transferers.py:472-486) without the zeros + scatter + cat + permute passes
       move_rows_body<VEC, false>(
@@ -2086,17 +2169,19 @@ __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
 #else
 #define SPP_DELIVER_ATTR
 #endif
-template <int VEC>
+// kP2P: the assembly reads remote rows in their owners' partitions (a kernel of its own: its wider source records must
+// not cost the default delivery registers -- 76 = six waves per SIMD)
+template <int VEC, bool kP2P = false>
 __global__ __launch_bounds__(kGatherThreads) SPP_DELIVER_ATTR void k_deliver(DeliverArgs a) {
   static_assert(kGatherThreads == kNT, "one workgroup shape for all three parts");
-  deliver_body<VEC>(a, (int)blockIdx.x);
+  deliver_body<VEC, kP2P>(a, (int)blockIdx.x);
 }
 
-template <int VEC>
+template <int VEC, bool kP2P = false>
 __global__ __launch_bounds__(kGatherThreads) void k_deliver_group(const DeliverArgs* __restrict__ args, GroupBlocks gb) {
   int i = 0;
   while (i + 1 < gb.n && (int)blockIdx.x >= gb.start[i + 1]) ++i;  // uniform: a handful of scalar compares
-  deliver_body<VEC>(args[i], (int)blockIdx.x - gb.start[i]);
+  deliver_body<VEC, kP2P>(args[i], (int)blockIdx.x - gb.start[i]);
 }
 
 }  // namespace spp
@@ -3223,16 +3308,52 @@ static spp_status fill_deliver_args(spp_sampler* s, int slot, const spp_mfg_out*
     a.cache = asrc->cache;
     a.psrc = sl.p.psrc;
     for (int m = 0; m < s->part.P; ++m) a.recv_base[m] = asrc->recv_base[m];
+    if (asrc->p2p) {
+      a.p2p = 1;
+      a.p2p_stride = asrc->peer_stride > 0 ? asrc->peer_stride : x_row_bytes;
+      for (int m = 0; m < s->part.P; ++m) {
+        SPP_REQUIRE(m == s->part.rank || hs->pcnt[m] == 0 || asrc->peer[m], "sampler_deliver: no table of peer %d", m);
+        a.recv_base[m] = (int64_t)reinterpret_cast<uintptr_t>(asrc->peer[m]) - s->part.off.v[m] * a.p2p_stride;
+      }
+    }
     SPP_REQUIRE(hs->pcnt[s->part.P] == 0 || asrc->cache, "sampler_deliver: cache hits without cache rows");
+  }
+  // row references instead of rows (spp_mfg_out.row_addr; the caller passes no x destination)
+  if (mfg && mfg->row_addr && !x_dst && (x_src || asrc) && U > 0 && x_row_bytes > 0) {
+    if (x_src_stride <= 0) x_src_stride = x_row_bytes;
+    a.x_src = static_cast<const char*>(x_src);
+    a.x_src_stride = x_src_stride;
+    a.x_rows = U;
+    a.x_row_bytes = x_row_bytes;
+    a.addr_out = mfg->row_addr;
+    a.nb_a = (int32_t)std::min<int64_t>(ceil_div(U, 4 * kNT), 512);
+    if (asrc && !asrc->p2p) {
+      int64_t remote = 0;
+      for (int m = 0; m < s->part.P; ++m) {
+        a.xr_cnt[m] = (m == s->part.rank) ? 0 : hs->pcnt[m];
+        remote += a.xr_cnt[m];
+      }
+      if (remote > 0) {
+        SPP_REQUIRE(mfg->x_remote, "sampler_deliver: row references of a batch with %lld received rows need x_remote",
+                    (long long)remote);
+        a.xr_dst = static_cast<char*>(mfg->x_remote);
+        a.nb_r = (int32_t)std::min<int64_t>(ceil_div(remote * x_row_bytes, 16 * 4 * kNT), 1024);
+      }
+    }
   }
   if ((x_src || asrc) && x_dst && U > 0 && x_row_bytes > 0) {  // a rank may own no rows at all (x_local NULL)
     if (x_src_stride <= 0) x_src_stride = x_row_bytes;
     SPP_REQUIRE(x_src_stride >= x_row_bytes, "spp_session_export: source stride %lld smaller than the row (%lld bytes)",
                 (long long)x_src_stride, (long long)x_row_bytes);
     uintptr_t align_probe = reinterpret_cast<uintptr_t>(x_src);
-    if (asrc)
+    if (asrc) {
       align_probe |= reinterpret_cast<uintptr_t>(asrc->recv) | reinterpret_cast<uintptr_t>(asrc->cache) |
                      (uintptr_t)a.cache_stride;
+      if (asrc->p2p) {
+        align_probe |= (uintptr_t)a.p2p_stride;
+        for (int m = 0; m < s->part.P; ++m) align_probe |= reinterpret_cast<uintptr_t>(asrc->peer[m]);
+      }
+    }
     const GatherGeom gg = gather_geometry(reinterpret_cast<const void*>(align_probe), x_dst, x_row_bytes, U, x_src_stride,
                                           /*allow_span=*/!asrc);  // (received rows are dense: no padding to read into)
     a.x_src_stride = x_src_stride;
@@ -3265,16 +3386,26 @@ spp_status sampler_deliver(spp_sampler* s, int slot, const spp_mfg_out* mfg, con
   int vec = 1;
   SPP_TRY(fill_deliver_args(s, slot, mfg, x_src, x_row_bytes, x_src_stride, x_dst, y_src, y_row_bytes, y_rows, y_dst, asrc,
                             a, &vec));
-  const unsigned grid = (unsigned)(a.nb_x + a.nb_e + a.nb_y);
+  const unsigned grid = (unsigned)(a.nb_x + a.nb_a + a.nb_r + a.nb_e + a.nb_y);
   if (grid == 0) return SPP_OK;
   const int prof = prof_begin(SPP_PROF_GATHER, st, a.x_rows);
-  switch (vec) {
-    case kVecSpan: hipLaunchKernelGGL(k_deliver<kVecSpan>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(k_deliver<16>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_deliver<8>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_deliver<4>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_deliver<2>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
-    default: hipLaunchKernelGGL(k_deliver<1>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+  if (a.p2p && a.nb_x > 0) {
+    switch (vec) {
+      case 16: hipLaunchKernelGGL((k_deliver<16, true>), dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 8: hipLaunchKernelGGL((k_deliver<8, true>), dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((k_deliver<4, true>), dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((k_deliver<2, true>), dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      default: hipLaunchKernelGGL((k_deliver<1, true>), dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    }
+  } else {
+    switch (vec) {
+      case kVecSpan: hipLaunchKernelGGL(k_deliver<kVecSpan>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 16: hipLaunchKernelGGL(k_deliver<16>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 8: hipLaunchKernelGGL(k_deliver<8>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 4: hipLaunchKernelGGL(k_deliver<4>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(k_deliver<2>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+      default: hipLaunchKernelGGL(k_deliver<1>, dim3(grid), dim3(kGatherThreads), 0, st, a); break;
+    }
   }
   prof_end(SPP_PROF_GATHER, prof, st);
   SPP_HIP_TRY(hipGetLastError());
@@ -3308,7 +3439,7 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
     if (i == 0) vec = v;
     else if (vec != v) vec = std::min(vec == kVecSpan ? 8 : vec, v == kVecSpan ? 8 : v);
     gb.start[i] = (int32_t)blocks;
-    blocks += ha[i].nb_x + ha[i].nb_e + ha[i].nb_y;
+    blocks += ha[i].nb_x + ha[i].nb_a + ha[i].nb_r + ha[i].nb_e + ha[i].nb_y;
     rows += ha[i].x_rows;
   }
   if (blocks == 0) return SPP_OK;
@@ -3327,8 +3458,10 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
     ha[i].nb_x = (int32_t)std::min<int64_t>(ha[i].nb_x, cap_x);
     ha[i].nb_e = (int32_t)std::min<int64_t>(ha[i].nb_e, 96);
     ha[i].nb_y = (int32_t)std::min<int64_t>(ha[i].nb_y, 4);
+    ha[i].nb_a = (int32_t)std::min<int64_t>(ha[i].nb_a, 64);
+    ha[i].nb_r = (int32_t)std::min<int64_t>(ha[i].nb_r, cap_x);
     gb.start[i] = (int32_t)blocks;
-    blocks += ha[i].nb_x + ha[i].nb_e + ha[i].nb_y;
+    blocks += ha[i].nb_x + ha[i].nb_a + ha[i].nb_r + ha[i].nb_e + ha[i].nb_y;
   }
   gb.start[n] = (int32_t)blocks;
   // a narrower access width than a batch was laid out for: its lanes-per-row geometry follows the common width
@@ -3345,13 +3478,23 @@ spp_status sampler_deliver_group(spp_sampler* s, int set, int first_slot, int n,
   SPP_HIP_TRY(hipMemcpyAsync(s->dargs_dev[set], ha, sizeof(DeliverArgs) * (size_t)n, hipMemcpyHostToDevice, st));
   const int prof = prof_begin(SPP_PROF_GATHER, st, rows);
   const DeliverArgs* da = s->dargs_dev[set];
-  switch (vec) {
-    case kVecSpan: hipLaunchKernelGGL(k_deliver_group<kVecSpan>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
-    case 16: hipLaunchKernelGGL(k_deliver_group<16>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
-    case 8: hipLaunchKernelGGL(k_deliver_group<8>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
-    case 4: hipLaunchKernelGGL(k_deliver_group<4>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
-    case 2: hipLaunchKernelGGL(k_deliver_group<2>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
-    default: hipLaunchKernelGGL(k_deliver_group<1>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+  if (asrc && asrc[0].p2p) {
+    switch (vec) {
+      case 16: hipLaunchKernelGGL((k_deliver_group<16, true>), dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 8: hipLaunchKernelGGL((k_deliver_group<8, true>), dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 4: hipLaunchKernelGGL((k_deliver_group<4, true>), dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 2: hipLaunchKernelGGL((k_deliver_group<2, true>), dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      default: hipLaunchKernelGGL((k_deliver_group<1, true>), dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    }
+  } else {
+    switch (vec) {
+      case kVecSpan: hipLaunchKernelGGL(k_deliver_group<kVecSpan>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 16: hipLaunchKernelGGL(k_deliver_group<16>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 8: hipLaunchKernelGGL(k_deliver_group<8>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 4: hipLaunchKernelGGL(k_deliver_group<4>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      case 2: hipLaunchKernelGGL(k_deliver_group<2>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+      default: hipLaunchKernelGGL(k_deliver_group<1>, dim3((unsigned)blocks), dim3(kGatherThreads), 0, st, da, gb); break;
+    }
   }
   prof_end(SPP_PROF_GATHER, prof, st);
   SPP_HIP_TRY(hipGetLastError());

@@ -102,6 +102,11 @@ struct AssembleSrc {
   const char* cache;
   int64_t x_local_stride, cache_stride;  // bytes between rows
   int64_t recv_base[SPP_MAX_PARTS];
+  // P2P transport (spp_exchange_cfg.peer_x_dev): segment m != rank is read in rank m's own partition -- row
+  // (node id - offsets[m]) of peer[m], rows peer_stride bytes apart; recv / recv_base are unused
+  bool p2p = false;
+  const char* peer[SPP_MAX_PARTS] = {};
+  int64_t peer_stride = 0;
 };
 
 // Fused delivery of the waited batch in `slot` to caller buffers in one launch on `st`:

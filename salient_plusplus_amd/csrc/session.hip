@@ -128,6 +128,10 @@ struct spp_session {
   std::vector<XSet> xsets;
   std::atomic<int64_t> sent_bytes{0}, recv_bytes{0};
   bool comm_failed = false;              // an exchange timed out / a peer left: comm_stream may never drain
+  // P2P transport (spp_exchange_cfg.peer_x_dev): no exchange at all -- the delivery reads remote rows in their owners' partitions
+  bool p2p = false;
+  const char* peer[SPP_MAX_PARTS] = {};
+  int64_t peer_stride = 0;
   // epoch arena of mt19937 streams (sampler_rng_arena); NULL: per-group generation into the slots
   const uint32_t* rng_base = nullptr;
   int64_t rng_stride = 0;
@@ -496,10 +500,11 @@ static spp_status wait_group_exchanged(spp_session* s, int64_t g) {
 }
 
 static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, const spp_partition_cfg& part) {
-  Transport* tr = comm_transport(xc->comm);
-  SPP_REQUIRE(tr, "spp_session_create: exchange without a communicator");
+  const bool p2p = xc->peer_x_dev != nullptr;
+  Transport* tr = p2p ? nullptr : comm_transport(xc->comm);
+  SPP_REQUIRE(tr || p2p, "spp_session_create: exchange without a communicator");
   SPP_REQUIRE(part.num_parts > 0, "spp_session_create: the native exchange needs spp_partition_cfg");
-  SPP_REQUIRE(tr->world() == part.num_parts && tr->rank() == part.rank,
+  SPP_REQUIRE(p2p || (tr->world() == part.num_parts && tr->rank() == part.rank),
               "spp_session_create: communicator is rank %d of %d but the partition book says %d of %d", tr->rank(),
               tr->world(), part.rank, part.num_parts);
   SPP_REQUIRE(xc->row_bytes > 0 && (xc->x_local_dev || xc->x_local_rows == 0), "spp_session_create: bad x_local");
@@ -517,6 +522,18 @@ static spp_status exchange_setup(spp_session* s, const spp_exchange_cfg* xc, con
   s->P = part.num_parts;
   s->rank = part.rank;
   s->rank_offset = part.offsets[part.rank];
+  if (p2p) {
+    // nothing to exchange: every remote row is read where it lives.  A rank that owns rows must be given their table.
+    s->peer_stride = xc->peer_x_stride_bytes > 0 ? xc->peer_x_stride_bytes : s->xcfg.x_local_stride_bytes;
+    SPP_REQUIRE(s->peer_stride >= xc->row_bytes, "spp_session_create: peer row stride smaller than the row");
+    for (int m = 0; m < s->P; ++m) {
+      s->peer[m] = static_cast<const char*>(xc->peer_x_dev[m]);
+      SPP_REQUIRE(m == s->rank || s->peer[m] || part.offsets[m + 1] == part.offsets[m],
+                  "spp_session_create: P2P transport without the table of rank %d", m);
+    }
+    s->p2p = true;
+    return SPP_OK;
+  }
   s->comm_stream = sampler_comm_stream(s->sampler);  // persistent, owned by the (pooled) sampler
   SPP_REQUIRE(s->comm_stream, "spp_session_create: no stream for the exchange");
   s->xsets.resize((size_t)s->num_sets);
@@ -865,7 +882,7 @@ extern "C" int spp_session_next(spp_session* s, spp_batch_desc* out) {
     s->blocked_us += us;
     s->blocked_occasions++;
   }
-  if (rc == SPP_OK && s->tr) rc = check_exchange_errors(s);
+  if (rc == SPP_OK && (s->tr || s->p2p)) rc = check_exchange_errors(s);
   if (rc != SPP_OK) return rc;
   if (b % s->G == 0) trace_ev('G', g);
   out->batch_index = b;
@@ -899,6 +916,24 @@ extern "C" int spp_session_try_next(spp_session* s, spp_batch_desc* out) {
   return spp_session_next(s, out);  // ready (or an error to report / a batch to drop): does not block now
 }
 
+// where the rows of batch `member` of group g come from (native exchange / P2P transport)
+static void fill_assemble_src(const spp_session* s, int64_t g, int member, AssembleSrc* src) {
+  *src = AssembleSrc{};
+  src->x_local = static_cast<const char*>(s->xcfg.x_local_dev);
+  src->cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
+  src->x_local_stride = s->xcfg.x_local_stride_bytes;
+  src->cache_stride = s->xcfg.cache_stride_bytes;
+  if (s->p2p) {
+    src->p2p = true;
+    src->peer_stride = s->peer_stride;
+    for (int m = 0; m < s->P; ++m) src->peer[m] = s->peer[m];
+    return;
+  }
+  const XSet& x = s->xsets[(size_t)(g % s->num_sets)];
+  src->recv = x.b->recv_rows;
+  for (int m = 0; m < s->P; ++m) src->recv_base[m] = x.recv_base[member][m];
+}
+
 extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg, const void* x_src_dev, int64_t x_rows,
                                          int64_t x_row_bytes, int64_t x_src_stride_bytes, void* x_out_dev,
                                          const void* y_src_dev, int64_t y_rows, int64_t y_row_bytes, void* y_out_dev,
@@ -918,18 +953,13 @@ extern "C" spp_status spp_session_export(spp_session* s, const spp_mfg_out* mfg,
   (void)y_rows;
   // one launch: MFG widening, x_s = serial_index(x, n_id) (fast_sampler.cpp:1006) and
   // y_s = serial_index(y, n_id, batch_size) (fast_sampler.cpp:1009)
-  if (s->tr) {
+  if (s->tr || s->p2p) {
     // x comes from the exchange: order the consumer after the group's rows and assemble in place
+    // (P2P transport: nothing was exchanged -- remote rows are read in their owners' partitions)
     const int64_t g = b / s->G;
-    const XSet& x = s->xsets[(size_t)(g % s->num_sets)];
-    SPP_HIP_TRY(hipStreamWaitEvent(as_stream(stream), x.rows_done, 0));
     AssembleSrc src{};
-    src.x_local = static_cast<const char*>(s->xcfg.x_local_dev);
-    src.recv = x.b->recv_rows;
-    src.cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
-    src.x_local_stride = s->xcfg.x_local_stride_bytes;
-    src.cache_stride = s->xcfg.cache_stride_bytes;
-    for (int m = 0; m < s->P; ++m) src.recv_base[m] = x.recv_base[b % s->G][m];
+    fill_assemble_src(s, g, (int)(b % s->G), &src);
+    if (s->tr) SPP_HIP_TRY(hipStreamWaitEvent(as_stream(stream), s->xsets[(size_t)(g % s->num_sets)].rows_done, 0));
     SPP_TRY(sampler_deliver(s->sampler, slot, mfg, nullptr, s->xcfg.row_bytes, 0, x_out_dev, y_src_dev, y_row_bytes,
                             bs, y_out_dev, &src, as_stream(stream)));
   } else {
@@ -1013,7 +1043,7 @@ extern "C" int spp_session_next_group(spp_session* s, int32_t block, spp_batch_d
     s->blocked_us += us;
     s->blocked_occasions++;
   }
-  if (rc == SPP_OK && s->tr) rc = check_exchange_errors(s);
+  if (rc == SPP_OK && (s->tr || s->p2p)) rc = check_exchange_errors(s);
   if (rc != SPP_OK) return rc;
   trace_ev('G', g);
   for (int i = 0; i < n; ++i) {
@@ -1053,21 +1083,12 @@ extern "C" spp_status spp_session_export_group(spp_session* s, int32_t n, const 
     bs[i] = (int64_t)r.second - r.first;
   }
   hipStream_t st = as_stream(stream);
-  if (s->tr) {
-    const XSet& x = s->xsets[(size_t)set];
-    SPP_HIP_TRY(hipStreamWaitEvent(st, x.rows_done, 0));
-    AssembleSrc src[kMaxGroup];
-    for (int i = 0; i < n; ++i) {
-      src[i] = AssembleSrc{};
-      src[i].x_local = static_cast<const char*>(s->xcfg.x_local_dev);
-      src[i].recv = x.b->recv_rows;
-      src[i].cache = static_cast<const char*>(s->xcfg.cache_feats_dev);
-      src[i].x_local_stride = s->xcfg.x_local_stride_bytes;
-      src[i].cache_stride = s->xcfg.cache_stride_bytes;
-      for (int m = 0; m < s->P; ++m) src[i].recv_base[m] = x.recv_base[i][m];
-    }
+  if (s->tr || s->p2p) {
+    if (s->tr) SPP_HIP_TRY(hipStreamWaitEvent(st, s->xsets[(size_t)set].rows_done, 0));
+    std::vector<AssembleSrc> src((size_t)n);
+    for (int i = 0; i < n; ++i) fill_assemble_src(s, g, i, &src[(size_t)i]);
     SPP_TRY(sampler_deliver_group(s->sampler, set, slot0, n, outs, nullptr, s->xcfg.row_bytes, 0, y_src_dev, y_row_bytes, bs,
-                                  src, st));
+                                  src.data(), st));
   } else {
     SPP_TRY(sampler_deliver_group(s->sampler, set, slot0, n, outs, x_src_dev, x_row_bytes, x_src_stride_bytes, y_src_dev,
                                   y_row_bytes, bs, nullptr, st));

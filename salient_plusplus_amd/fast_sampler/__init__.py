@@ -30,7 +30,8 @@ from .. import _native as nat
 
 __all__ = ["Config", "Session", "ProtoDistributedBatch", "RangePartitionBook", "Cache", "sample_adj",
            "multilayer_sample", "full_sample", "to_row_major", "serial_index", "NativeComm", "native_comm",
-           "set_native_comm", "async_errors", "set_sampler_options", "sampler_options", "sampler_info"]
+           "set_native_comm", "async_errors", "set_sampler_options", "sampler_options", "sampler_info", "TableRows", "RowRefs",
+           "P2PPeers", "set_p2p_peers", "p2p_open_peers"]
 
 # four slot-sets of 16 batches (~75 MB of workspace per slot at fanout [15,10,5], batch 1024: 4.8 GB).  With two sets, a
 # set's next sampling chain could only start once its previous group was consumed and the consumer waited on chain
@@ -162,6 +163,9 @@ def clear_resident_cache():
     global _graph_epoch
     _resident.clear()
     _SamplerPool.clear()
+    for peers in _p2p_auto.values():   # mappings of the peers' partitions (P2P transport): the tables they name may go away
+        peers.close()
+    _p2p_auto.clear()
     _graph_epoch += 1          # graphs uploaded from now on never share derived tables with earlier ones
 
 
@@ -237,6 +241,130 @@ class TableRows:
                                                      _ptr(self.n_id), 8, self.n_id.numel(), self.n_id.numel(), _ptr(out),
                                                      _stream_ptr()))
         return out
+
+
+class RowRefs:
+    """``x = cat(features_gather + [cached])[perm]`` (transferers.py:472-486) without the copy: what a PARTITIONED Session
+    with ``row_refs`` puts in the place of the batch's feature matrix.  ``addr[j]`` is the device address of the feature
+    row of MFG node j -- in this rank's resident partition, in the VIP cache, in a peer's partition (P2P transport) or in
+    ``x_remote`` (the rows received for this batch over RCCL: the only rows the delivery still copies).  ``models.SAGE``
+    aggregates its first layer straight from these addresses (spp_sage_operand_forward_rows: same rows, same summation
+    order as over the assembled matrix -- bit-identical operand); everything else sees a feature matrix through
+    ``materialize()``.  ``keep`` holds the tensors the addresses point into."""
+    __slots__ = ("addr", "n_id", "width", "_dtype", "x_remote", "keep")
+
+    def __init__(self, addr: torch.Tensor, n_id, width: int, dtype, x_remote, keep):
+        self.addr, self.n_id, self.width, self._dtype, self.x_remote, self.keep = addr, n_id, int(width), dtype, x_remote, keep
+
+    @property
+    def is_cuda(self):
+        return self.addr.is_cuda
+
+    @property
+    def device(self):
+        return self.addr.device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def shape(self):
+        return torch.Size((self.addr.numel(), self.width))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def numel(self):
+        return self.addr.numel() * self.width
+
+    def record_stream(self, stream):
+        for t in (self.addr, self.n_id, self.x_remote):
+            if t is not None and t.is_cuda:
+                t.record_stream(stream)                  # (the resident tables live as long as the Sessions' graph does)
+
+    def to(self, device=None, non_blocking=False, **_kw):
+        if device is None or torch.device(device) == self.addr.device:
+            return self
+        return self.materialize().to(device=device, non_blocking=non_blocking)
+
+    def materialize(self) -> torch.Tensor:
+        """The feature matrix itself (on the caller's current stream)."""
+        n = self.addr.numel()
+        out = torch.empty((n, self.width), dtype=self._dtype, device=self.addr.device)
+        if out.numel():
+            nat.check(_lib().spp_gather_row_refs(_ptr(self.addr), n, self.width * out.element_size(), _ptr(out), _stream_ptr()))
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# P2P transport: the peers' partitions mapped into this process (include/spp.h spp_exchange_cfg.peer_x_dev)
+# --------------------------------------------------------------------------------------------
+class P2PPeers:
+    """Base address, in THIS process, of every rank's resident partition (``ptrs[m]``; rows ``stride`` bytes apart)."""
+
+    def __init__(self, ptrs, stride, opened=(), keep=None):
+        self.ptrs, self.stride, self._opened, self.keep = [int(v) for v in ptrs], int(stride), list(opened), keep
+
+    def close(self):
+        L = nat.load()
+        for base in self._opened:
+            L.spp_ipc_close(C.c_void_p(base))
+        self._opened = []
+
+
+_p2p_tls = threading.local()
+_p2p_auto = {}
+
+
+def set_p2p_peers(peers):
+    """Pin the peer tables the P2P Sessions created by THIS thread use: a P2PPeers, a list of the ranks' resident
+    partitions (in-process ranks: plain device tensors, rows padded alike), or None = automatic (p2p_open_peers)."""
+    if peers is not None and not isinstance(peers, P2PPeers):
+        tabs = list(peers)
+        ref = next(t for t in tabs if t is not None and t.numel())
+        peers = P2PPeers([t.data_ptr() if t is not None and t.numel() else 0 for t in tabs], _stride_bytes(ref) or
+                         ref.size(1) * ref.element_size(), keep=tabs)
+    _p2p_tls.peers = peers
+
+
+def p2p_open_peers(x_local: torch.Tensor, group=None) -> P2PPeers:
+    """COLLECTIVE over `group` (any torch.distributed backend): every rank exports its resident partition `x_local`
+    (hipIpcGetMemHandle of the allocation that holds it), the handles travel by all_gather_object, and every rank maps
+    its peers' partitions (hipIpcOpenMemHandle).  The ranks must run on one node; peer access between their GPUs is
+    enabled lazily by the runtime.  Close the result only after a barrier (a peer may still be reading)."""
+    import torch.distributed as dist
+    L = _lib()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    handle = (C.c_ubyte * nat.SPP_IPC_HANDLE_BYTES)()
+    off = C.c_int64(0)
+    mine = None
+    if x_local is not None and x_local.numel():
+        nat.check(L.spp_ipc_export(C.c_void_p(x_local.data_ptr()), handle, C.byref(off)))
+        mine = (bytes(handle), int(off.value), os.getpid(), int(x_local.data_ptr()),
+                _stride_bytes(x_local) or x_local.size(1) * x_local.element_size())
+    got = [None] * world
+    dist.all_gather_object(got, mine, group=group)
+    ptrs, opened, stride = [], [], 0
+    for m, rec in enumerate(got):
+        if rec is None:
+            ptrs.append(0)
+            continue
+        stride = stride or rec[4]
+        if rec[4] != stride:
+            raise RuntimeError("P2P transport: the ranks' partitions have different row strides")
+        if m == rank or rec[2] == os.getpid():           # my own table / a rank of this very process
+            ptrs.append(rec[3])
+            continue
+        buf = (C.c_ubyte * nat.SPP_IPC_HANDLE_BYTES).from_buffer_copy(rec[0])
+        base = C.c_void_p()
+        nat.check(L.spp_ipc_open(buf, _device().index, C.byref(base)))
+        opened.append(int(base.value))
+        ptrs.append(int(base.value) + rec[1])
+    return P2PPeers(ptrs, stride, opened, keep=x_local)
 
 
 # --------------------------------------------------------------------------------------------
@@ -662,13 +790,32 @@ class Session:
         self.compact_native_records = False
         self._native_feats = {}
         self._cache_feats = None
+        self.p2p = False
+        self._peers = None
         if self._distributed:
-            comm = native_comm()
             pb = config.partition_book
-            if comm is not None and self._x is not None and \
-                    (comm.world, comm.rank) == (int(pb.world_size), int(pb.rank)):
+            # P2P transport (opt-in, SPP_DIST_TRANSPORT=p2p): remote rows are read in their owners' partitions, no exchange
+            p2p = os.environ.get("SPP_DIST_TRANSPORT", "rccl").lower() == "p2p" and self._x is not None
+            if p2p:
+                peers = getattr(_p2p_tls, "peers", None)
+                if peers is None:
+                    key = (self._x.data_ptr(), int(pb.world_size), int(pb.rank))
+                    peers = _p2p_auto.get(key)
+                    if peers is None:
+                        peers = _p2p_auto[key] = p2p_open_peers(self._x)      # collective, once per resident table
+                if len(peers.ptrs) != int(pb.world_size):
+                    raise RuntimeError(f"P2P transport: {len(peers.ptrs)} peer tables for {int(pb.world_size)} partitions")
+                self._peers = peers
+            comm = None if p2p else native_comm()
+            if self._x is not None and (p2p or (comm is not None and
+                                                (comm.world, comm.rank) == (int(pb.world_size), int(pb.rank)))):
                 xc = nat.ExchangeCfg()
-                xc.comm = comm.handle
+                xc.comm = None if p2p else comm.handle
+                if p2p:
+                    self._peer_arr = (C.c_void_p * len(peers.ptrs))(*[v or None for v in peers.ptrs])
+                    xc.peer_x_dev = C.cast(self._peer_arr, C.POINTER(C.c_void_p))
+                    xc.peer_x_stride_bytes = peers.stride
+                    self.p2p = True
                 xc.x_local_dev, xc.x_local_rows = self._x.data_ptr(), self._x.size(0)
                 xc.row_bytes = self._x.size(1) * self._x.element_size()
                 xc.x_local_stride_bytes = _stride_bytes(self._x)
@@ -717,6 +864,11 @@ class Session:
         # delivery launch skips the feature gather (labels + MFG + n_id are still delivered) -- for models.SAGE's
         # fused first layer.  Set before the first batch is asked for; SPP_TABLE_FEATURES=1 sets it for every Session.
         self.table_features = os.environ.get("SPP_TABLE_FEATURES", "0") != "0"
+        # the same for PARTITIONED sessions with the native exchange / P2P transport: the records carry
+        # RowRefs(addresses of the rows: local partition / cache / received rows / a peer's partition) in the place of x;
+        # the delivery writes 8 bytes per row (+ a contiguous copy of the rows received over RCCL) instead of assembling x.
+        # SPP_ROW_REFS=1 sets it for every such Session.
+        self.row_refs = os.environ.get("SPP_ROW_REFS", "0") != "0" and self.native_exchange
         self.export_stream = None                  # set by a consumer that delivers on ONE fixed stream (DevicePrefetcher): the
         self._export_raw = None                    # per-batch path then skips the current-stream lookup / stream context
         self.last_arenas = None                    # the (<= 3) storages behind the views of the batch handed out last
@@ -960,7 +1112,17 @@ class Session:
             return False
         if self._distributed or self._x is None:
             raise RuntimeError("table_features: only single-GPU sessions with a feature table deliver TableRows "
-                               "(a partitioned session assembles x from three sources)")
+                               "(a partitioned session assembles x from three sources: set row_refs there)")
+        return True
+
+    def _refs_mode(self) -> bool:
+        if not self.row_refs:
+            return False
+        if not (self._distributed and self.native_exchange and self._x is not None):
+            raise RuntimeError("row_refs: only partitioned sessions with the native exchange (RCCL or P2P transport) deliver "
+                               "RowRefs (single-GPU sessions: table_features)")
+        if not (self._group_mode or self._member_mode):
+            raise RuntimeError("row_refs needs group fetch (SPP_GROUP_FETCH=0 is not supported)")
         return True
 
     def _next_member(self, block: bool):
@@ -1019,14 +1181,15 @@ class Session:
         count_remote = distributed and bool(cfg.count_remote_frequency) and not use_cache
         want_parts = distributed and (not native or count_remote or not self.compact_native_records)
         table = self._table_mode()
+        refs = self._refs_mode()
         want_n_id = distributed or table
-        want_x = (self._x is not None) and (native or not distributed) and not table
+        want_x = (self._x is not None) and (native or not distributed) and not table and not refs
         want_y = self._y is not None
         H = int(self._gdescs[0].counts.num_hops)
         # ---- sizes (host counts of every batch) and the arena layout
         seg = []                                      # lengths of all int64 segments, batch after batch
         info = []
-        Us, bss = [], []
+        Us, bss, n_rem = [], [], []
         for i in range(n):
             d = self._gdescs[i]
             c = d.counts
@@ -1038,6 +1201,8 @@ class Session:
             first = len(seg)
             if want_n_id:
                 seg.append(U)
+            if refs:
+                seg.append(U)                          # one address per row
             for k in range(H):
                 seg.append(Ts[k] + 1)
                 seg.append(Es[k])
@@ -1048,6 +1213,8 @@ class Session:
             info.append((first, U, Ts, Ss, Es, pc, int(d.start), int(d.stop)))
             Us.append(U)
             bss.append(int(d.stop) - int(d.start))
+            if refs:                                   # rows received over RCCL for this batch (P2P: none are copied)
+                n_rem.append(0 if self.p2p else U - int(c.part_counts[rank]) - (int(c.part_counts[P]) if use_cache else 0))
         # arena sizes are rounded up to a coarse grid (<= 3 %): group totals differ by fractions of a percent from
         # group to group, and the caching allocator would otherwise keep meeting sizes no cached block fits
         n_seg = sum(seg)
@@ -1071,6 +1238,18 @@ class Session:
             x_arena = torch.empty((_coarse(n_rows), F), dtype=self._x.dtype, device=dev)
             x_views = x_arena.split(x_split + [x_arena.size(0) - n_rows])[0::2]
             x_base = x_arena.data_ptr()
+        xr_arena = xr_views = None
+        if refs:
+            F = self._x.size(1)
+            row_b = F * self._x.element_size()
+            xr_align = 16 // math.gcd(row_b, 16)        # every batch's received rows start 16-byte aligned
+            xr_split = []
+            for r_ in n_rem:
+                xr_split += [r_, (-r_) % xr_align]
+            if sum(n_rem):
+                xr_arena = torch.empty((_coarse(sum(xr_split)), F), dtype=self._x.dtype, device=dev)
+                xr_views = xr_arena.split(xr_split + [xr_arena.size(0) - sum(xr_split)])[0::2]
+                xr_base = xr_arena.data_ptr()
         if want_y:
             y_arena = torch.empty((sum(bss), self._y.size(1)), dtype=self._y.dtype, device=dev)
             y_views = y_arena.split(bss)
@@ -1078,7 +1257,7 @@ class Session:
         outs = (nat.GroupOut * n)()
         e_id = self._e_id
         off = 0                                       # running element offset into the int64 arena
-        xo = yo = 0
+        xo = yo = xro = 0
         records = []
         for i in range(n):
             first, U, Ts, Ss, Es, pc, start, stop = info[i]
@@ -1088,6 +1267,12 @@ class Session:
             if want_n_id:
                 n_id = views[k]
                 o.mfg.n_id = (base + 8 * off) if U else None
+                off += U
+                k += 1
+            addr = None
+            if refs:
+                addr = views[k]
+                o.mfg.row_addr = (base + 8 * off) if U else None
                 off += U
                 k += 1
             adjs = []
@@ -1115,6 +1300,13 @@ class Session:
             x = y = None
             if table:
                 x = TableRows(self._x, n_id)
+            if refs:
+                xr = None
+                if n_rem[i]:
+                    xr = xr_views[i]
+                    o.mfg.x_remote = xr_base + xro * row_b
+                    xro += n_rem[i] + (-n_rem[i]) % xr_align
+                x = RowRefs(addr, n_id, self._x.size(1), self._x.dtype, xr, (self._x, self._cache_feats, self._peers))
             if want_x:
                 x = x_views[i]
                 o.x_out = (x_base + xo * row_b) if U else None
@@ -1126,7 +1318,7 @@ class Session:
             records.append((x, y, adjs, (start, stop), n_id, nids, flat, cached, perm, pc, U))
         xa = self._x_args if (want_x and not native) else (None, 0, 0, 0)
         ya = self._y_args if want_y else (None, 0, 0)
-        arenas = [t for t in (arena, x_arena if want_x else None, y_arena if want_y else None) if t is not None]
+        arenas = [t for t in (arena, x_arena if want_x else None, y_arena if want_y else None, xr_arena) if t is not None]
         return n, outs, records, xa, ya, (distributed, native, count_remote, rank), arenas
 
     def _proto_record(self, x, y, adjs, rng, n_id, nids, flat, cached, perm, pc, native, count_remote, rank):

@@ -273,8 +273,14 @@ class FastSamplerIter(Iterator[PreparedBatch]):
     """One epoch: owns the native Session (``.session``) and yields its batches in index order."""
     session: fast_sampler.Session
 
-    def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig, table_features: bool = False):
+    def __init__(self, num_threads: int, max_items_in_queue: int, cfg: FastSamplerConfig, table_features: bool = False,
+                 row_refs: bool = False):
         self.session = fast_sampler.Session(num_threads, max_items_in_queue, cfg.to_fast_sampler())
+        if row_refs:
+            # opt-in, partitioned sessions with the native exchange / P2P transport: PreparedBatch.x is
+            # fast_sampler.RowRefs (where every row lives) and the delivery assembles nothing; models.SAGE aggregates its
+            # first layer from the addresses, anything else calls .materialize()
+            self.session.row_refs = True
         if table_features:
             # opt-in: PreparedBatch.x is fast_sampler.TableRows(resident table, n_id) and the delivery skips the feature
             # gather; models.SAGE aggregates its first layer straight from the table, anything else calls .materialize()
@@ -321,9 +327,10 @@ class FastSampler(ABCNeighborSampler):
     cfg: FastSamplerConfig
     # not in the reference (samplers.py:381-399 has the three fields above): see FastSamplerIter
     table_features: bool = False
+    row_refs: bool = False
 
     def __iter__(self):
-        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg, self.table_features)
+        return FastSamplerIter(self.num_threads, self.max_items_in_queue, self.cfg, self.table_features, self.row_refs)
 
     def __len__(self):
         return self.cfg.get_num_batches()

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _native as nat
-from .fast_sampler import TableRows
+from .fast_sampler import RowRefs, TableRows
 
 
 def _p(t):
@@ -206,8 +206,10 @@ class SAGE(torch.nn.Module):
             weights = [w for conv in self.convs for w in (conv.lin_l.weight, conv.lin_r.weight)]
             if isinstance(x, TableRows):                 # fused first layer: the batch's rows are read from the table
                 x = (x.table, x.n_id)
+            elif isinstance(x, RowRefs):                 # ... or wherever the partitioned path found them
+                x = _Refs(x)
             return _SageStack.apply(x, hops, self.training, 0.5, *weights)
-        if isinstance(x, TableRows):
+        if isinstance(x, (TableRows, RowRefs)):
             x = x.materialize()
         for i, (adj_t, _e_id, size) in enumerate(adjs):
             x_target = x[:size[1]]
@@ -253,6 +255,14 @@ def _tall_linear(a, w):
     return torch.nn.functional.linear(a, w)
 
 
+class _Refs:
+    """RowRefs on their way through _SageStack.apply (a non-tensor argument)"""
+    __slots__ = ("r",)
+
+    def __init__(self, r):
+        self.r = r
+
+
 class _SageStack(torch.autograd.Function):
     """The whole SAGE forward (all layers: fused operand, one GEMM, ReLU + dropout; log_softmax) as ONE
     autograd node with a hand-written backward.  The kernels are the ones the layer-wise path uses; what
@@ -264,9 +274,14 @@ class _SageStack(torch.autograd.Function):
     def usable(model, x, adjs):
         if isinstance(x, TableRows):                     # (resident table, n_id): the first layer reads the table itself
             x = x.table
-        if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.float16, torch.float32) or x.requires_grad:
+        if isinstance(x, RowRefs):                       # addresses of the rows
+            if x.dtype not in (torch.float16, torch.float32) or x.width % 4:
+                return False
+            k = x.width
+        elif x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.float16, torch.float32) or x.requires_grad:
             return False
-        k = x.size(1)
+        else:
+            k = x.size(1)
         for conv in model.convs:
             if conv.lin_l.bias is not None or conv.lin_l.weight.dtype != torch.float32 or k % 4:
                 return False
@@ -279,15 +294,21 @@ class _SageStack(torch.autograd.Function):
         nat.require_device()
         n_layers = len(hops)
         st = _stream()
-        n_id = None
+        n_id = refs = None
         if isinstance(x, tuple):                         # (table, n_id) of a TableRows: batch row j = table[n_id[j]]
             x, n_id = x
+        elif isinstance(x, _Refs):                       # RowRefs: batch row j = the row at address addr[j]
+            refs = x.r
+            x = refs.addr
         h = x
         operands, acts, wcats, seeds = [], [], [], []
         for i, (rowptr, col, T) in enumerate(hops):
-            K = h.size(1)
+            K = refs.width if (i == 0 and refs is not None) else h.size(1)
             A = torch.empty((T, 2 * K), dtype=torch.float32, device=x.device)
-            if i == 0 and n_id is not None:
+            if i == 0 and refs is not None:
+                nat.check(L.spp_sage_operand_forward_rows(_p(rowptr), _p(col), T, _p(refs.addr), int(refs.dtype == torch.float16),
+                                                          K, _p(A), 2 * K, st))
+            elif i == 0 and n_id is not None:
                 nat.check(L.spp_sage_operand_forward_table(_p(rowptr), _p(col), T, _p(h), int(h.dtype == torch.float16),
                                                            h.stride(0) if h.size(0) > 1 else K, h.size(0), _p(n_id), K,
                                                            _p(A), 2 * K, st))
@@ -315,7 +336,7 @@ class _SageStack(torch.autograd.Function):
         ctx.save_for_backward(*operands, *acts, *wcats, out, *hop_t)
         ctx.hop_T = [int(T) for (_r, _c, T) in hops]
         ctx.act = (float(p), int(bool(training)), seeds)
-        ctx.src_rows = [x.size(0) if n_id is None else n_id.numel()] + [a.size(0) for a in acts]
+        ctx.src_rows = [(x.numel() if refs is not None else x.size(0)) if n_id is None else n_id.numel()] + [a.size(0) for a in acts]
         return out
 
     @staticmethod
@@ -526,7 +547,7 @@ class GAT(torch.nn.Module):
             conv.apply(init_weights)
 
     def forward(self, x, adjs):
-        if isinstance(x, TableRows):                     # (the fused first layer exists for SAGE)
+        if isinstance(x, (TableRows, RowRefs)):                     # (the fused first layer exists for SAGE)
             x = x.materialize()
         # the reference converts the features to fp32 first (models.py:221); GATConv here reads the fp16
         # rows directly (exact: every fp16 value is an fp32 value)

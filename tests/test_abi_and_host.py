@@ -41,9 +41,9 @@ def test_struct_layouts_match_header():
     prog = r'''
 #include <stdio.h>
 #include "spp.h"
-int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(spp_sampler_cfg), sizeof(spp_mfg_counts),
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(spp_sampler_cfg), sizeof(spp_mfg_counts),
                         sizeof(spp_mfg_out), sizeof(spp_session_cfg), sizeof(spp_batch_desc), sizeof(spp_sampler_opts),
-                        sizeof(spp_sampler_info)); return 0; }
+                        sizeof(spp_sampler_info), sizeof(spp_exchange_cfg), sizeof(spp_group_out)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -53,7 +53,7 @@ int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(spp_sampler_cfg)
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(nat.SamplerCfg), ctypes.sizeof(nat.MfgCounts), ctypes.sizeof(nat.MfgOut),
                      ctypes.sizeof(nat.SessionCfg), ctypes.sizeof(nat.BatchDesc), ctypes.sizeof(nat.SamplerOpts),
-                     ctypes.sizeof(nat.SamplerInfo)]
+                     ctypes.sizeof(nat.SamplerInfo), ctypes.sizeof(nat.ExchangeCfg), ctypes.sizeof(nat.GroupOut)]
 
 
 def test_product_fails_loudly_without_gpu():
