@@ -93,6 +93,10 @@ def parse():
     ap.add_argument("--epochs", type=int, default=4,
                     help="WHOLE epochs timed wall-clock per leg (iterator creation -> last batch -> synchronize), the first "
                          "reported separately as the reference does (fast_trainer/train.py:223-316 drops it); 0 = skip")
+    ap.add_argument("--p2p-leg", action="store_true",
+                    help="partitioned path: after the default (RCCL) windows, a second short leg over the opt-in P2P transport "
+                         "(SPP_DIST_TRANSPORT=p2p: remote rows read in their owners' partitions, mapped through HIP IPC); its "
+                         "figures are appended under `exchange_p2p`, the line's value stays the RCCL one")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the partitioned / RCCL exchange path even with one rank (rehearsal of the N>1 code)")
     return ap.parse_args()
@@ -915,6 +919,40 @@ def main():
                 gc.collect()
                 _trace("measuring whole epochs (with the model step)")
                 epoch_measured["with_model_step"] = run_epochs(make_iter, step)
+            if distributed and native and a.model == "sage" and not a.no_fused_leg:
+                # Row g1 on the partitioned path: Session(row_refs) delivers MFG + labels + where every row lives (local
+                # partition / cache / the rows received for the batch) and models.SAGE's first layer reads from there
+                # (spp_sage_operand_forward_rows; bit-identical operand, tests/test_gpu_row_refs_p2p.py)
+                feeder.quiesce()
+                feeder.devit = None
+                gc.collect()
+                dist.barrier()
+                refs_sampler = FastSampler(4, a.slots, cfg, row_refs=True)
+
+                def make_refs_iter(idx):
+                    refs_sampler.idx = idx
+                    return DeviceDistributedPrefetcher([dev], iter(refs_sampler), pipeline_on=True)
+                refs_feeder = EpochFeeder(make_refs_iter, shuffler, get_idx)
+                r_step = make_model_step(F, n_classes, a.hidden, layers, hip=True, arch=a.model, ddp=True)
+                r_only, r_data, r_detail = model_step_timing(refs_feeder, r_step)
+                refs_feeder.quiesce()
+                t = torch.tensor([r_only, r_data], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                r_only, r_data = (float(v) for v in t.cpu().tolist())
+                model_out["model_step"]["fused_first_layer"] = {
+                    "what": "Session(row_refs): the delivery writes one address per row (+ a contiguous copy of the rows received "
+                            "over RCCL), SAGE layer 1 reads the rows where they live (spp_sage_operand_forward_rows)",
+                    "ms_per_step_model_only_resident_batch": r_only, "ms_per_step_with_data_path": r_data,
+                    "data_path_cost_ms": r_data - r_only, "epoch_time_s_with_model_step": nb_epoch * r_data / 1e3,
+                    "timing": r_detail}
+                model_out["model_step"]["data_path_cost_ms"] = m_data - m_only
+                if epoch_measured is not None:
+                    refs_feeder.devit = None
+                    gc.collect()
+                    epoch_measured["with_model_step_fused_first_layer"] = run_epochs(make_refs_iter, r_step)
+                refs_feeder.devit = None
+                del r_step
+                gc.collect()
             if not distributed and a.model == "sage" and not a.no_fused_leg:
                 # Row g1: the opt-in fused consumer.  The Session delivers MFG + labels + n_id and NO feature rows
                 # (PreparedBatch.x = TableRows(resident table, n_id)); models.SAGE's first layer aggregates straight from
@@ -953,6 +991,69 @@ def main():
             if distributed:
                 raise                                 # a rank that fell out of a collective sequence: fail loudly
             model_out = {"model_step": {"error": repr(e)}}
+    # ---- opt-in second leg: the same partitioned workload over the P2P transport ----
+    p2p_out = None
+    if distributed and a.p2p_leg:
+        feeder.quiesce()
+        feeder.devit = None
+        gc.collect()
+        dist.barrier()
+        transport_before = os.environ.get("SPP_DIST_TRANSPORT")
+        os.environ["SPP_DIST_TRANSPORT"] = "p2p"
+        try:
+            import dataclasses
+            p2p_sampler = FastSampler(4, a.slots, cfg)
+
+            def make_p2p_iter(idx):
+                p2p_sampler.idx = idx
+                return DeviceDistributedPrefetcher([dev], iter(p2p_sampler), pipeline_on=True)
+            # parity first: a group of batches against the full table every rank holds
+            n_check = min(8, max(1, n_local // bs))
+            vcfg = dataclasses.replace(cfg, idx=get_idx()[:n_check * bs].contiguous(), exact_num_batches=n_check)
+            vit = iter(FastSampler(4, a.slots, vcfg))            # (collective: the peers' partitions are mapped here)
+            good = bool(vit.session.p2p)
+            for proto in vit:
+                good = good and proto.x is not None and bool(torch.equal(proto.x, wl.x[proto.n_id]))
+            vit.session.close()
+            del vit
+            flags = torch.tensor([1 if good else 0], device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            p_feeder = EpochFeeder(make_p2p_iter, shuffler, get_idx)
+            for _ in range(a.prime + a.warmup):
+                p_feeder.next()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            pw = []
+            for _w in range(max(2, R // 2)):
+                e_ = 0
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    e_ += count_edges(p_feeder.next())
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                pw.append((time.perf_counter() - t0, float(e_)))
+            st_ = torch.tensor(pw, dtype=torch.float64, device=dev)
+            tmax = st_[:, 0].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            etot = st_[:, 1].clone()
+            dist.all_reduce(etot, op=dist.ReduceOp.SUM)
+            p_dt = float(tmax.mean())
+            p2p_out = {"transport": "P2P: remote rows read in the owner's partition inside the delivery (no id exchange, no serve gather, "
+                                    "no send / receive buffers); peers mapped through hipIpcOpenMemHandle",
+                       "verified_bit_exact_vs_full_table": bool(int(flags.item())),
+                       "windows": len(pw), "steps_each": a.steps, "ms_per_step": p_dt / a.steps * 1e3,
+                       "value": float(etot.mean()) / p_dt, "ms_per_step_all": [round(float(v) / a.steps * 1e3, 5) for v in tmax.cpu().tolist()],
+                       "vs_rccl": (dt / a.steps) / (p_dt / a.steps)}
+            p_feeder.devit = None
+            gc.collect()
+            dist.barrier()
+        finally:
+            if transport_before is None:
+                os.environ.pop("SPP_DIST_TRANSPORT", None)
+            else:
+                os.environ["SPP_DIST_TRANSPORT"] = transport_before
     if epoch_measured is not None:
         # measured against extrapolated (batches x ms/step of the windows), per leg
         ext = {"data_path_only": nb_epoch * (dt / a.steps)}
@@ -1118,6 +1219,8 @@ def main():
                                "rank0_received_MB_per_batch": recv / n_timed / 1e6,
                                "rank0_GBps_out": sent / timed_total_s / 1e9, "rank0_GBps_in": recv / timed_total_s / 1e9,
                                "xgmi_peak_GBps_per_gpu": 7 * 153.0}
+        if p2p_out is not None:
+            out["exchange_p2p"] = p2p_out
         if model_out is not None:
             out.update(model_out)
         if not a.no_cpu_baseline and not distributed:

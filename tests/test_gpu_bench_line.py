@@ -101,14 +101,21 @@ def test_single_gpu_line():
 
 
 def test_partitioned_path_line_with_the_ddp_leg():
-    d = _run(["--gpus", "1", "--force-distributed", "--no-cpu-baseline"])
+    d = _run(["--gpus", "1", "--force-distributed", "--no-cpu-baseline", "--p2p-leg"])
     _check_common(d, 1)
     assert "range-partitioned" in d["config"]["parallelism"]
     m = d["model_step"]
     assert "DistributedDataParallel" in m["model"] and m["ms_per_step_with_data_path"] > 0
     ex = d.get("exchange")
     assert ex is not None and ex.get("rccl_world") == 1
-    _check_epochs(d, ["data_path_only", "with_model_step"])
+    _check_epochs(d, ["data_path_only", "with_model_step", "with_model_step_fused_first_layer"])
+    # row g1 where the metric lives: the partitioned path's fused consumer (row references) under its own key
+    f = m["fused_first_layer"]
+    assert "row_refs" in f["what"] and f["ms_per_step_with_data_path"] > 0
+    assert abs(f["data_path_cost_ms"] - (f["ms_per_step_with_data_path"] - f["ms_per_step_model_only_resident_batch"])) < 1e-9
+    # the opt-in P2P leg: parity checked against the full table, figures beside (not instead of) the RCCL line's
+    p2p = d["exchange_p2p"]
+    assert p2p["verified_bit_exact_vs_full_table"] is True and p2p["ms_per_step"] > 0 and p2p["value"] > 0
 
 
 def test_model_shape_flags():
