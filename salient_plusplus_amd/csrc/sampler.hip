@@ -2123,13 +2123,27 @@ __device__ __forceinline__ void deliver_body(const DeliverArgs& a, int b) {
                                      a.nb_x, a.x_src_stride);
     } else if constexpr (kP2P) {
       // P2P transport: a remote row is read in its owner's partition (xGMI), at row (node id - offsets[m])
-      struct Key { int2 c; int32_t nid; };
+      // (the peers' bases through LDS: indexing the by-value argument block with a per-lane owner made the compiler keep a
+      // private copy of it -- 1.4 KB of scratch per lane)
+      __shared__ int64_t peer_base[SPP_MAX_PARTS];
+      for (int m = 0; m < a.P; ++m)
+        if ((int)threadIdx.x == m) peer_base[m] = a.recv_base[m];
+      __syncthreads();
+      const int2* __restrict__ psrc = a.psrc;
+      const int32_t* __restrict__ nids = a.n_ids;
+      const char* xl = a.x_src;
+      const char* xc = a.cache;
+      const int64_t xs = a.x_src_stride, cs = a.cache_stride, ps = a.p2p_stride;
+      const int32_t rank = a.rank, P = a.P;
       move_rows_body<VEC, false>(
-          [&](int64_t r) { return Key{a.psrc[r], a.n_ids[r]}; },
-          [&](Key k) -> const char* {
-            if (k.c.x == a.rank) return a.x_src + (int64_t)k.c.y * a.x_src_stride;
-            if (k.c.x == a.P) return a.cache + (int64_t)k.c.y * a.cache_stride;
-            return reinterpret_cast<const char*>(a.recv_base[k.c.x]) + (int64_t)k.nid * a.p2p_stride;
+          [=](int64_t r) {
+            const int2 c = psrc[r];
+            return int4{c.x, c.y, nids[r], 0};
+          },
+          [=](int4 k) -> const char* {
+            if (k.x == rank) return xl + (int64_t)k.y * xs;
+            if (k.x == P) return xc + (int64_t)k.y * cs;
+            return reinterpret_cast<const char*>(peer_base[k.x]) + (int64_t)k.z * ps;
           },
           a.x_rows, a.x_row_bytes, a.x_chunks, a.x_lpr_log2, a.x_dst, b, a.nb_x);
     } else {
