@@ -4,7 +4,10 @@ transport: everything above send / recv / all-gather is the product path) at S-p
 local / cache-hit / fetched composition of its batches and the rows it served, and the per-batch time (ranks share
 one GPU: NOT a performance number).  Run under rocprofv3 (--kernel-trace --stats, or one --pmc counter) for the
 per-kernel figures of k_serve_rows / k_pack_remote_ids / k_gpart_* / k_deliver at that load (tools/exchange_p8.sh).
-usage: [WL=S-papers CACHE_FRAC=0.1 CACHE_STRATEGY=vip] exchange_p8.py [P=8] [batches per rank=24] [epochs=2]"""
+TRANSPORT=p2p: the opt-in P2P transport (remote rows read in the owner's partition: no exchange kernels at all);
+ROW_REFS=1: the records carry RowRefs (one address per row + a contiguous copy of the received rows) instead of the
+assembled matrix (verified through materialize()).
+usage: [WL=S-papers CACHE_FRAC=0.1 CACHE_STRATEGY=vip TRANSPORT=local|p2p ROW_REFS=0|1] exchange_p8.py [P=8] [batches per rank=24] [epochs=2]"""
 import json
 import os
 os.environ.setdefault("SPP_ALLOW_LOCAL_COMM", "1")   # rehearsal transport: opt-in
@@ -33,7 +36,15 @@ N, F = wl.num_nodes, wl.x.size(1)
 offsets = torch.linspace(0, N, P + 1).long()
 offsets[-1] = N
 off_dev = offsets.to(dev)
-comms = fs.NativeComm.local(P)
+TRANSPORT = os.environ.get("TRANSPORT", "local")
+ROW_REFS = os.environ.get("ROW_REFS", "0") != "0"
+x_parts = [wl.x[int(offsets[r]):int(offsets[r + 1])].contiguous() for r in range(P)]
+if TRANSPORT == "p2p":
+    os.environ["SPP_DIST_TRANSPORT"] = "p2p"
+    comms = []
+    peer_tables = [fs._resident.get_rows(t) for t in x_parts]       # what the ranks' Sessions keep resident
+else:
+    comms = fs.NativeComm.local(P)
 res, errors = {}, []
 # every rank runs the same number of batches (force_exact_num_batches): the smallest pool of own training vertices decides
 own = torch.bincount(torch.searchsorted(off_dev, wl.train_idx, right=True) - 1, minlength=P)
@@ -43,7 +54,10 @@ NB = min(NB, int(own.min()) // wl.batch_size)
 def rank_main(r):
     try:
         torch.cuda.set_device(0)
-        fs.set_native_comm(comms[r])
+        if TRANSPORT == "p2p":
+            fs.set_p2p_peers(peer_tables)
+        else:
+            fs.set_native_comm(comms[r])
         lo, hi = int(offsets[r]), int(offsets[r + 1])
         pb = fs.RangePartitionBook(r, P, offsets)
         bs = wl.batch_size
@@ -61,19 +75,19 @@ def rank_main(r):
             g.manual_seed(1000 * epoch + r)
             idx = mine[torch.randperm(mine.numel(), generator=g).to(dev)][:nb * bs].contiguous()
             cfg = FastSamplerConfig(
-                x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=wl.x[lo:hi].contiguous(), y=wl.y.unsqueeze(-1),
+                x_cpu=torch.empty((0, F), dtype=wl.x.dtype), x_gpu=x_parts[r], y=wl.y.unsqueeze(-1),
                 rowptr=wl.rowptr, col=wl.col, idx=idx, batch_size=bs, sizes=wl.fanouts, skip_nonfull_batch=False,
                 pin_memory=False, distributed=True, partition_book=pb, cache=cache, force_exact_num_batches=True,
                 exact_num_batches=nb, count_remote_frequency=False, use_cache=True)
-            it = iter(FastSampler(2, int(os.environ.get("SPP_MAX_SLOTS_DIST", "64")), cfg))
-            assert it.session.native_exchange
+            it = iter(FastSampler(2, int(os.environ.get("SPP_MAX_SLOTS_DIST", "64")), cfg, row_refs=ROW_REFS))
+            assert it.session.native_exchange and it.session.p2p == (TRANSPORT == "p2p")
             t0 = time.perf_counter()
             n = 0
             ok = True
             for b in it:                                              # the native records carry x (assembled) and n_id
                 n += 1
                 if os.environ.get("VERIFY", "1") != "0":
-                    ok = ok and bool(torch.equal(b.x, wl.x[b.n_id]))
+                    ok = ok and bool(torch.equal(b.x.materialize() if ROW_REFS else b.x, wl.x[b.n_id]))
                 loc = (b.n_id >= lo) & (b.n_id < hi)
                 hit = ~loc & in_cache[b.n_id]
                 rem = ~loc & ~hit
@@ -89,9 +103,11 @@ def rank_main(r):
     except BaseException as e:  # noqa: BLE001
         import traceback
         errors.append(f"rank {r}: {e}\n{traceback.format_exc()}")
-        comms[r].close()
+        if comms:
+            comms[r].close()
     finally:
         fs.set_native_comm(None)
+        fs.set_p2p_peers(None)
 
 
 ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(P)]
@@ -120,7 +136,7 @@ for r in range(P):
           f"bit exact {all(res[(r, e)]['bit_exact'] for e in range(EPOCHS))}; " +
           ", ".join(f"epoch {e}: {res[(r, e)]['us_per_batch']:.0f} us/batch" for e in range(EPOCHS)))
 s = sum(tot)
-summary = {"P": P, "cache_frac": CACHE_FRAC, "cache_strategy": CACHE_STRATEGY, "cache_rows_per_rank": int(CACHE_FRAC * N / P),
+summary = {"P": P, "transport": TRANSPORT, "row_refs": ROW_REFS, "cache_frac": CACHE_FRAC, "cache_strategy": CACHE_STRATEGY, "cache_rows_per_rank": int(CACHE_FRAC * N / P),
            "exchange_bytes_per_batch_and_rank": [sum(res[(r, e)]["exchange_bytes"][k] for r in range(P) for e in range(EPOCHS)) / max(1, nbatches)
                                                   for k in (0, 1)],
            "workload": wl.name, "F": F, "row_bytes": 2 * F, "batches_all_ranks": nbatches, "rows_delivered": s,
