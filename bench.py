@@ -880,6 +880,7 @@ def main():
     # which chain variant ran and what its one-off tables cost (read before the timed Session goes away)
     sess0 = getattr(getattr(feeder.devit, "it", None), "session", None)
     sinfo = sess0.sampler_info() if sess0 is not None else {}
+    del sess0        # (a live reference would keep the Session, and with it the pooled sampler, away from the next one)
     if a.epochs > 0:
         if distributed:
             feeder.quiesce()
