@@ -399,6 +399,9 @@ def model_step_timing(feeder, step, steps=64, warm=16, windows=6):
     a2 = n_dev_allocs()
     detail = {"windows": windows, "steps_each": steps, "warmup_steps": warm, "warmup_steps_with_data_path": warm_data,
               "reported": "mean over all windows",
+              # (the medians: robust against one allocator stall -- at S-mag on ONE GPU 98 % of the HBM is in use and torch's
+              # caching allocator meets a retry, ~1 s, somewhere in the with-data windows)
+              "model_only_ms_median": sorted(w_only)[len(w_only) // 2], "with_data_path_ms_median": sorted(w_data)[len(w_data) // 2],
               "model_only_ms_all": [round(v, 4) for v in w_only], "with_data_path_ms_all": [round(v, 4) for v in w_data],
               # hipMalloc calls of torch's caching allocator during each leg (warm-up included)
               "torch_device_allocs": {"resident_batch": a1 - a0, "with_data_path": a2 - a1}}
