@@ -103,7 +103,12 @@ spp_status spp_gather_rows(const void* src_dev, int64_t src_rows, int64_t row_by
                            void* dst_dev, void* stream);
 /* Same, for a source table whose rows are src_stride_bytes apart (>= row_bytes; 0 = dense).  The
  * resident feature table is kept with rows padded to the 128-B HBM fetch granule: a 200-B row then
- * costs 2 granules instead of 2.56 on average.  dst stays dense. */
+ * costs 2 granules instead of 2.56 on average.  dst stays dense.
+ * READABLE EXTENT: the table must hold src_rows * src_stride_bytes readable bytes (not just (src_rows - 1) * stride +
+ * row_bytes): for rows of 16k + 8 bytes out of a 16-byte-aligned table with a 16-byte-multiple stride >= row_bytes + 8
+ * the gather moves 16-byte pieces and the last piece of a row reads 8 bytes of that row's padding (never written;
+ * spp_tune("gather_span", 0) keeps the 8-byte form, which reads row_bytes per row exactly).  The same holds for
+ * spp_exchange_cfg.x_local_dev and the table of spp_session_export. */
 spp_status spp_gather_rows_strided(const void* src_dev, int64_t src_rows, int64_t row_bytes,
                                    int64_t src_stride_bytes, const void* idx_dev, int idx_elem_bytes,
                                    int64_t n_idx, int64_t n_out, void* dst_dev, void* stream);
