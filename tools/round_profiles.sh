@@ -17,8 +17,9 @@ timeout -k 10 400 python3 bench.py > "$out/${tag}_bench_papers.json" 2> "$out/be
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-model-step --no-cpu-baseline > "$out/${tag}_bench_papers_steps20.json" 2>> "$out/bench.err" || exit 1
 timeout -k 10 300 python3 bench.py --workload S-products --no-cpu-baseline --no-model-step > "$out/${tag}_bench_products.json" 2>> "$out/bench.err" || exit 1
 timeout -k 10 300 python3 bench.py --gpus 1 --force-distributed --no-cpu-baseline --no-model-step > "$out/${tag}_bench_papers_force_distributed.json" 2>> "$out/bench.err" || exit 1
-# kernel statistics + timeline of the default command (model step and CPU leg off: they are not the data path)
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "${tag}_bench_papers" -- python3 bench.py --no-cpu-baseline --no-model-step > "$out/prof_bench.json" 2>> "$out/bench.err" || exit 1
+# kernel statistics + timeline of the default command (model step, CPU leg and the whole-epoch legs off: the statistics
+# then cover priming + warm-up + the timed windows, the launches the line's live HIP-event timing samples)
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o "${tag}_bench_papers" -- python3 bench.py --no-cpu-baseline --no-model-step --epochs 0 > "$out/prof_bench.json" 2>> "$out/bench.err" || exit 1
 f=$(find "$out" -name "${tag}_bench_papers_kernel_trace.csv" | head -1)
 python3 tools/trace_report.py "$f" 192 > "$out/${tag}_pipeline_trace_report.txt"
 rm -f "$f" "$out"/${tag}_bench_papers_agent_info.csv "$out"/${tag}_bench_papers_domain_stats.csv
