@@ -148,7 +148,7 @@ typedef struct spp_sampler_opts {
   int32_t col32;            /* int32 copy of `col` (SPP_COL32; auto: on).  Off: the kernels read the int64 array        */
   int32_t deg_tags;         /* degree tags in the spare top bits of the int32 entries (SPP_DEG_TAGS; auto: on when
                                ids leave >= 3 bits spare; used by a sampler only when every later fanout < the cap)     */
-  int32_t row_stubs;        /* 128-byte row-stub table (SPP_ROW_STUBS; auto: when it takes <= 1/4 of the free HBM)      */
+  int32_t row_stubs;        /* 128-byte row-stub table (SPP_ROW_STUBS; auto: when it takes <= 1/8 of the free HBM)      */
   int32_t rng_arena;        /* mt19937 streams of a whole epoch generated once and kept (auto: when the arena fits
                                rng_arena_mb and, without an explicit budget, 1/4 of the free HBM); off: per group
                                into the slots' ping-pong buffers (k_rng_fill)                                          */

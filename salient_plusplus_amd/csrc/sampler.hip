@@ -2294,7 +2294,7 @@ struct SlotHost {
 struct ResolvedOpts {
   int col32 = 1;             // 0 / 1
   int deg_tags = 1;          // 0 / 1 (wanted; whether the ids leave room is decided when the array is built)
-  int row_stubs = -1;        // 0 off, 1 always, -1 when a quarter of the free HBM holds them
+  int row_stubs = -1;        // 0 off, 1 always, -1 when an eighth of the free HBM holds them
   int rng_arena = -1;        // 0 per-group generation, 1 arena whenever it fits the budget, -1 also the free-HBM rule
   int64_t rng_arena_words = 0;  // budget
   int fuse = 1;              // 0 never, 1 rule, 2 wherever the kernel can
@@ -2650,9 +2650,9 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
       s->bytes += (int64_t)sizeof(int32_t) * cfg->nnz;
     }
   }
-  // Row stubs (128 B per node): SPP_ROW_STUBS=0 off, =1 always; default: when they take at most a quarter
-  // of the memory that is free right now (the caller may still have tensors to place).  Only the fast path
-  // uses them.
+  // Row stubs (128 B per node): spp_sampler_opts.row_stubs / SPP_ROW_STUBS=0 off, =1 always; default: when they take at
+  // most an eighth of the memory that is free right now (the caller still has tensors to place: the outputs of the
+  // batches in flight, the model's activations).  Only the fast path uses them.
   if (rc == SPP_OK && cfg->nnz > 0 && cfg->num_nodes > 0 && !s->any_generic && s->opt.row_stubs != 0) {
     const int mode = s->opt.row_stubs;
     const size_t need = sizeof(int32_t) * kStubInts * (size_t)cfg->num_nodes;
@@ -2662,7 +2662,9 @@ extern "C" spp_status spp_sampler_create(const spp_sampler_cfg* cfg, spp_sampler
     std::shared_ptr<RowStubs> c = g_stubs[key].lock();
     if (!c) {
       size_t free_b = 0, total_b = 0;
-      const bool room = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 4);
+      // (an EIGHTH since round 6: at S-mag on one GPU -- 187 GB of features -- a quarter admitted the 15.6 GB table, the
+      // chain was not measurably faster with it, and torch's caching allocator, left with 4 GB, met retries of ~1 s)
+      const bool room = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 8);
       if (room) {
         const auto t0 = std::chrono::steady_clock::now();
         c = std::make_shared<RowStubs>();
@@ -2983,8 +2985,8 @@ spp_status sampler_rng_arena(spp_sampler* s, const uint32_t* seeds, int64_t nb, 
   const int64_t need = stride_w * nb;
   if (need > s->opt.rng_arena_words) return SPP_OK;
   if (need > s->rng_arena_words && s->opt.rng_arena < 0) {
-    // no explicit budget: a new arena may take at most a quarter of the HBM that is free right now (the row stubs
-    // follow the same rule); otherwise the streams are generated per group into the slots
+    // no explicit budget: a new arena may take at most a quarter of the HBM that is free right now; otherwise the streams
+    // are generated per group into the slots
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)need * 4 > free_b / 4) return SPP_OK;
   }

@@ -173,8 +173,8 @@ def test_mag_fullsize_epoch_properties():
     torch.cuda.synchronize()
     try:
         assert wl.x.shape == (121_751_666, 768) and wl.fanouts == [25, 15]
-        # Which chain variant the library picks here is decided by the free HBM (128 B x N of row stubs against a quarter of
-        # what is free after the 187 GB of features: a knife edge) -- so the run records what it picked, and BOTH sides of
+        # Which chain variant the library picks here is decided by the free HBM (128 B x N of row stubs against an eighth of
+        # what is free after the 187 GB of features; a quarter, the rule until round 6, was a knife edge) -- so the run records what it picked, and BOTH sides of
         # every such rule run at full size and must deliver the same batches (digest per batch).  The variants' own
         # oracle parity is tests/test_gpu_sampler_variants.py.
         auto_d, auto_info = [], {}

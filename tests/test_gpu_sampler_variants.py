@@ -3,7 +3,7 @@ or the fan-outs -- computes the same batches (sample_adj, sample_cpu.hpp:25-143;
 fast_sampler.cpp:191-227; per-batch seeding :994).  The automatic rules (include/spp.h spp_sampler_opts) are pinned
 one way and the other through the sampler configuration, inside ONE process:
 
-  * no row stubs (the S-mag knife edge: 128 B x N against a quarter of the free HBM) -- degrees from rowptr,
+  * no row stubs (S-mag on one GPU: 128 B x N exceeds an eighth of the free HBM) -- degrees from rowptr,
     cooperative reads of the int32 array (k_hop_pick<int32, no stub>);
   * no degree tags (a fan-out >= the tag cap) -- the degree pass reads the stub headers (k_hop_pick<int32, stub>);
   * the int64 neighbour array, with and without stubs (k_hop_pick<int64, ...>);
