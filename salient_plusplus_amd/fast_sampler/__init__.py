@@ -1214,7 +1214,7 @@ class Session:
             Us.append(U)
             bss.append(int(d.stop) - int(d.start))
             if refs:                                   # rows received over RCCL for this batch (P2P: none are copied)
-                n_rem.append(0 if self.p2p else U - int(c.part_counts[rank]) - (int(c.part_counts[P]) if use_cache else 0))
+                n_rem.append(0 if self.p2p else U - int(c.part_counts[rank]) - int(c.part_counts[P]))
         # arena sizes are rounded up to a coarse grid (<= 3 %): group totals differ by fractions of a percent from
         # group to group, and the caching allocator would otherwise keep meeting sizes no cached block fits
         n_seg = sum(seg)
