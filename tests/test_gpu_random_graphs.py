@@ -47,13 +47,21 @@ def _graph(rng, n, mean_deg, zero_frac, n_hubs, hub_share):
 @settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
 @given(seed=st.integers(0, 2**31 - 1), n=st.integers(40, 6000), mean_deg=st.floats(0.5, 40.0), zero_frac=st.floats(0.0, 0.5),
        n_hubs=st.integers(0, 3), hub_share=st.floats(0.0, 0.6), sizes=st.sampled_from(FANOUTS), bs=st.sampled_from([1, 7, 64, 256, 1024]),
-       n_batches=st.integers(1, 9), slots=st.sampled_from([1, 2, 5, 16, 64]), dup=st.booleans())
-def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs, n_batches, slots, dup):
+       n_batches=st.integers(1, 9), slots=st.sampled_from([1, 2, 5, 16, 64]), dup=st.booleans(),
+       variant=st.sampled_from([None, None, None, dict(row_stubs=False), dict(deg_tags=False), dict(col32=False), dict(rng_arena=False),
+                                dict(flag_tiled=False, rows_coalesced=False), dict(fuse_scatter=-1), dict(fuse_scatter=2),
+                                dict(col32=False, row_stubs=False, rng_arena=False), dict(initial_edge_cap=256)]))
+def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs, n_batches, slots, dup, variant=None):
+    """(round 6: `variant` pins one of the chain's forms -- include/spp.h spp_sampler_opts -- for the case's samplers)"""
     from oracle import oracle as orc
+    if variant:
+        with fs.sampler_options(**variant):
+            return test_random_graph_against_the_oracle.hypothesis.inner_test(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs,
+                                                                              n_batches, slots, dup, None)
     if os.environ.get("SPP_FUZZ_LOG"):          # the case about to run: the last line names the one that hung or crashed
         with open(os.environ["SPP_FUZZ_LOG"], "a") as f:
             f.write(repr(dict(seed=seed, n=n, mean_deg=mean_deg, zero_frac=zero_frac, n_hubs=n_hubs, hub_share=hub_share, sizes=sizes,
-                              bs=bs, n_batches=n_batches, slots=slots, dup=dup)) + "\n")
+                              bs=bs, n_batches=n_batches, slots=slots, dup=dup, variant=dict(fs._sampler_opts))) + "\n")
     rng = np.random.default_rng(seed)
     rowptr, col = _graph(rng, n, mean_deg, zero_frac, n_hubs, hub_share)
     n_idx = max(1, min(bs * n_batches - int(rng.integers(0, bs)), 4 * n))
