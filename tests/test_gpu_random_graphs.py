@@ -51,7 +51,7 @@ def _graph(rng, n, mean_deg, zero_frac, n_hubs, hub_share):
        variant=st.sampled_from([None, None, None, dict(row_stubs=False), dict(deg_tags=False), dict(col32=False), dict(rng_arena=False),
                                 dict(flag_tiled=False, rows_coalesced=False), dict(fuse_scatter=-1), dict(fuse_scatter=2),
                                 dict(col32=False, row_stubs=False, rng_arena=False), dict(initial_edge_cap=256)]))
-def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs, n_batches, slots, dup, variant=None):
+def test_random_graph_against_the_oracle(fs, seed, n, mean_deg, zero_frac, n_hubs, hub_share, sizes, bs, n_batches, slots, dup, variant):
     """(round 6: `variant` pins one of the chain's forms -- include/spp.h spp_sampler_opts -- for the case's samplers)"""
     from oracle import oracle as orc
     if variant:
@@ -99,7 +99,7 @@ def test_larger_random_graph_with_hubs_against_the_oracle(fs, k):
     duplicates, 16 slots): the sizes hypothesis rarely draws"""
     test_random_graph_against_the_oracle.hypothesis.inner_test(
         fs, seed=1000 + k, n=20_000, mean_deg=12.0 + k, zero_frac=0.05, n_hubs=3, hub_share=0.4, sizes=FANOUTS[k], bs=512,
-        n_batches=5, slots=16, dup=bool(k & 1))
+        n_batches=5, slots=16, dup=bool(k & 1), variant=None)
 
 
 @settings(max_examples=EXAMPLES, deadline=None, derandomize=DERANDOMIZE, suppress_health_check=list(HealthCheck))
