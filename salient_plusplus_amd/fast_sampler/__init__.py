@@ -325,10 +325,21 @@ def set_p2p_peers(peers):
     partitions (in-process ranks: plain device tensors, rows padded alike), or None = automatic (p2p_open_peers)."""
     if peers is not None and not isinstance(peers, P2PPeers):
         tabs = list(peers)
-        ref = next(t for t in tabs if t is not None and t.numel())
-        peers = P2PPeers([t.data_ptr() if t is not None and t.numel() else 0 for t in tabs], _stride_bytes(ref) or
-                         ref.size(1) * ref.element_size(), keep=tabs)
+        peers = P2PPeers([t.data_ptr() if t is not None and t.numel() else 0 for t in tabs],
+                         _common_stride([_table_stride_bytes(t) for t in tabs if t is not None and t.numel()]), keep=tabs)
     _p2p_tls.peers = peers
+
+
+def _table_stride_bytes(t: torch.Tensor) -> int:
+    """Bytes between the rows of a resident partition.  A table of ONE row has no stride of its own: it follows the rule
+    every resident table is laid out by (_row_stride_elems), which is what its peers' tables use."""
+    return _stride_bytes(t) or _row_stride_elems(t.size(1), t.element_size()) * t.element_size()
+
+
+def _common_stride(strides) -> int:
+    if len(set(strides)) != 1:
+        raise RuntimeError(f"P2P transport: the ranks' partitions must share one row stride, got {sorted(set(strides))}")
+    return int(strides[0])
 
 
 def p2p_open_peers(x_local: torch.Tensor, group=None) -> P2PPeers:
@@ -344,18 +355,15 @@ def p2p_open_peers(x_local: torch.Tensor, group=None) -> P2PPeers:
     mine = None
     if x_local is not None and x_local.numel():
         nat.check(L.spp_ipc_export(C.c_void_p(x_local.data_ptr()), handle, C.byref(off)))
-        mine = (bytes(handle), int(off.value), os.getpid(), int(x_local.data_ptr()),
-                _stride_bytes(x_local) or x_local.size(1) * x_local.element_size())
+        mine = (bytes(handle), int(off.value), os.getpid(), int(x_local.data_ptr()), _table_stride_bytes(x_local))
     got = [None] * world
     dist.all_gather_object(got, mine, group=group)
-    ptrs, opened, stride = [], [], 0
+    ptrs, opened = [], []
+    stride = _common_stride([rec[4] for rec in got if rec is not None])
     for m, rec in enumerate(got):
         if rec is None:
             ptrs.append(0)
             continue
-        stride = stride or rec[4]
-        if rec[4] != stride:
-            raise RuntimeError("P2P transport: the ranks' partitions have different row strides")
         if m == rank or rec[2] == os.getpid():           # my own table / a rank of this very process
             ptrs.append(rec[3])
             continue

@@ -220,6 +220,26 @@ def test_p2p_transport_in_process_ranks(P, use_cache, nb, bs, slots, F, refs, mo
     _run_ranks(P, "p2p", use_cache, nb, bs, slots, refs, F, monkeypatch)
 
 
+def test_p2p_partition_of_one_row_follows_the_resident_stride(monkeypatch):
+    """A rank that owns ONE vertex: its table has no stride of its own, and 400-byte rows are kept 512 bytes apart in every
+    resident table -- the peers' stride must be that rule's, not the row length (found by the random suite in round 6)."""
+    from salient_plusplus_amd import fast_sampler as fs
+    monkeypatch.setenv("SPP_DIST_TRANSPORT", "p2p")
+    g = _graph(200)
+    n = g["rowptr"].shape[0] - 1
+    offsets = [0, 1, n]
+    xg = [T(g["x"][offsets[r]:offsets[r + 1]].copy()).cuda() for r in range(2)]
+    tables = _Peers([fs._resident.get_rows(t) for t in xg], xg)
+    errors = []
+    ts = [threading.Thread(target=_run_rank, args=(r, 2, "p2p", None, tables, g, offsets, False, 3, 16, 8, r == 1, errors)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(240)
+    assert not errors, "\n".join(errors)
+    fs.clear_resident_cache()
+
+
 def test_group_delivery_with_row_refs(monkeypatch):
     """one delivery launch per sampling group (SPP_GROUP_DELIVERY=1): the same references, the same copies"""
     monkeypatch.setenv("SPP_GROUP_DELIVERY", "1")
