@@ -283,3 +283,30 @@ def test_table_rows_reads_like_the_feature_matrix():
     f = {fld.name: fld for fld in dataclasses.fields(FastSampler)}
     assert list(f)[:3] == ["num_threads", "max_items_in_queue", "cfg"]           # the reference's three (samplers.py:381-399)
     assert f["table_features"].default is False
+
+
+def test_sampler_options_and_p2p_stride_rules_host_side():
+    """Host-only logic of round 6: option names are checked, booleans map to +1 / -1, the context manager restores; the row
+    stride of a one-row partition follows the resident tables' rule; peers with different strides are refused."""
+    from salient_plusplus_amd import fast_sampler as fs
+    from salient_plusplus_amd import _native as nat
+    fs.set_sampler_options()
+    with pytest.raises(RuntimeError):
+        fs.set_sampler_options(no_such_option=1)
+    with fs.sampler_options(row_stubs=False, rng_arena=True, fuse_scatter=2, col32=0):
+        assert fs._sampler_opts == {"row_stubs": -1, "rng_arena": 1, "fuse_scatter": 2}
+        with fs.sampler_options(deg_tags=False):
+            assert fs._sampler_opts == {"deg_tags": -1}
+        assert fs._sampler_opts == {"row_stubs": -1, "rng_arena": 1, "fuse_scatter": 2}
+    assert fs._sampler_opts == {}
+    assert set(fs._OPT_FIELDS) | {"reserved"} == {n for n, _t in nat.SamplerOpts._fields_}
+    one = torch.zeros((1, 200), dtype=torch.float16)              # 400-byte rows live 512 bytes apart in a resident table
+    many = torch.zeros((5, 256), dtype=torch.float16)[:, :200]
+    assert fs._table_stride_bytes(one) == 512 == fs._table_stride_bytes(many)
+    assert fs._table_stride_bytes(torch.zeros((1, 128), dtype=torch.float16)) == 256
+    assert fs._common_stride([512, 512]) == 512
+    with pytest.raises(RuntimeError):
+        fs._common_stride([512, 400])
+    r = fs.RowRefs(torch.zeros(7, dtype=torch.int64), None, 12, torch.float16, None, ())
+    assert tuple(r.shape) == (7, 12) and r.size(0) == 7 and r.dim() == 2 and r.numel() == 84 and r.dtype == torch.float16
+    assert r.to() is r
