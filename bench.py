@@ -1053,6 +1053,27 @@ def main():
             p_feeder.devit = None
             gc.collect()
             dist.barrier()
+            if not a.no_model_step and a.model == "sage" and not a.no_fused_leg:
+                # ... and the consumer this transport is meant for: row references on top (remote rows are not even copied:
+                # the first layer reads them in their owners' HBM), under DistributedDataParallel like the default legs
+                os.environ["SPP_EXCHANGE_ISSUE"] = "consumer"
+                pr_sampler = FastSampler(4, a.slots, cfg, row_refs=True)
+
+                def make_pr_iter(idx):
+                    pr_sampler.idx = idx
+                    return DeviceDistributedPrefetcher([dev], iter(pr_sampler), pipeline_on=True)
+                pr_feeder = EpochFeeder(make_pr_iter, shuffler, get_idx)
+                pr_step = make_model_step(F, 47, a.hidden, a.layers if a.layers > 0 else len(sizes), hip=True, arch=a.model, ddp=True)
+                pr_only, pr_data, pr_detail = model_step_timing(pr_feeder, pr_step)
+                t = torch.tensor([pr_only, pr_data], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                pr_only, pr_data = (float(v) for v in t.cpu().tolist())
+                p2p_out["model_step_row_refs"] = {"ms_per_step_model_only_resident_batch": pr_only, "ms_per_step_with_data_path": pr_data,
+                                                  "data_path_cost_ms": pr_data - pr_only, "timing": pr_detail}
+                pr_feeder.devit = None
+                del pr_step
+                gc.collect()
+                dist.barrier()
         finally:
             if transport_before is None:
                 os.environ.pop("SPP_DIST_TRANSPORT", None)

@@ -116,6 +116,7 @@ def test_partitioned_path_line_with_the_ddp_leg():
     # the opt-in P2P leg: parity checked against the full table, figures beside (not instead of) the RCCL line's
     p2p = d["exchange_p2p"]
     assert p2p["verified_bit_exact_vs_full_table"] is True and p2p["ms_per_step"] > 0 and p2p["value"] > 0
+    assert p2p["model_step_row_refs"]["ms_per_step_with_data_path"] > 0
 
 
 def test_model_shape_flags():
