@@ -1177,6 +1177,15 @@ def main():
                     roof_s["lone_chain"] = {"us_per_batch": us, "achieved_GBps_algorithmic": roof_s["algorithmic_bytes_per_batch"] / us / 1e3,
                                             "achieved_GBps_traffic": (roof_s["traffic"] / us / 1e3) if roof_s["traffic"] else None,
                                             "source": f"profiles/{os.path.basename(lone[-1])} (tools/microbench.py chain; NOT measured in this run)"}
+        # the step as a whole against the memory system: the HBM traffic of one batch (delivery + chain, from the committed PMC
+        # passes over this command) over the measured step
+        roof_p = None
+        if roof.get("traffic") and roof_s is not None and roof_s.get("traffic") and not distributed:
+            tot = roof["traffic"] + roof_s["traffic"]
+            ach = tot / (dt / a.steps) / 1e9
+            roof_p = {"bound": "hbm", "what": "the whole step: counter traffic of one batch's delivery + sampling chain over ms_per_step",
+                      "traffic_bytes_per_batch": tot, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                      "traffic_source": "profiles/ PMC passes (NOT measured in this run) x this run's step"}
         out = {
             "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -1229,6 +1238,7 @@ def main():
             "epoch_measured": epoch_measured,
             "roofline": roof,
             "roofline_sampler": roof_s,
+            "roofline_pipeline": roof_p,
         }
         if distributed and native:
             # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
