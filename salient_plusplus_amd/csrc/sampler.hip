@@ -3189,10 +3189,15 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // LDS table of k_bucket_dedup: 2048 / 4096 / 8192 / 16384 slots (any size works: multiply-shift slot index).
     // 3584 slots let five workgroups share a compute unit's LDS instead of four; measured: no difference
     // (lone chain 44-47 us per batch at 4096, 3584, 3072 and 2560 slots), so the roomier table stays.
+    // Measurement aid (profiles/r06_ab_INDEX.md): SPP_WHATIF_DEDUP_LDS_PAD=<bytes> of unused dynamic LDS per dedup workgroup of
+    // the LAST hop -- fewer of them fit a compute unit (24 KB: three instead of six), i.e. the kernel's wave-slot footprint
+    // beside the delivery shrinks while its own duration grows.  Results are unchanged.
+    static const unsigned dedup_pad = [] { const char* e = getenv("SPP_WHATIF_DEDUP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned dpad = (h == H - 1) ? dedup_pad : 0u;
     if (s->lds_log2 == 11)
-      hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
+      hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 12)
-      hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
+      hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 13)
       hipLaunchKernelGGL(k_bucket_dedup<8192>, dim3((nbk) * gy), dim3(kNT), 0, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else
