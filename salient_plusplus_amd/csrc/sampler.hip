@@ -771,10 +771,14 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
   // kHdr: the first eight draws are requested BEFORE the row's header is taken out of its stub line (the first use
   // of the line, i.e. the wait for it): stub line, offset sums and draws then share one round trip again, as they did
   // when the exact degree came from the degree pass
-  uint32_t rfirst[8];
+  // (sixteen draws / far picks per round trip in the fused instances -- the small hops' fan-outs of 10 and 15 would then need
+  // one round trip each instead of two -- measured nothing in round 6: 120 registers instead of 96, lone chain 34.5-35.0
+  // against 34.5-34.6 us per batch)
+  constexpr int kB = 8;
+  uint32_t rfirst[kB];
   if constexpr (kHdr) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rfirst[u] = rng[u < f ? u : (f > 0 ? f - 1 : 0)];  // (lanes that draw nothing read the stream's start)
+    for (int u = 0; u < kB; ++u) rfirst[u] = rng[u < f ? u : (f > 0 ? f - 1 : 0)];  // (lanes that draw nothing read the stream's start)
   }
   if constexpr (kCoop && kHdr) {
     // header {degree, row start lo, hi} of lane L's row: words 0..2 of the piece lane (L & 7) * 8 holds in round L >> 3
@@ -800,13 +804,13 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     // winner = option unless already chosen, then j.  The draws of 8 steps are loaded before the first
     // of them is used: the steps depend on each other through `chosen`, the loads do not, and under
     // the delivery kernel's HBM load one global round trip per step was most of this kernel's time.
-    for (int32_t k0 = 0; k0 < f; k0 += 8) {
-      uint32_t r[8];
+    for (int32_t k0 = 0; k0 < f; k0 += kB) {
+      uint32_t r[kB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)  // clamped, not predicated: the 8 loads issue back to back
+      for (int u = 0; u < kB; ++u)  // clamped, not predicated: the loads issue back to back
         r[u] = (kHdr && k0 == 0) ? rfirst[u] : rng[k0 + u < f ? k0 + u : f - 1];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kB; ++u) {
         const int32_t k = k0 + u;
         if (k >= f) break;
         if (replace) {  // sample_cpu.hpp:79-81
@@ -829,18 +833,18 @@ __global__ __launch_bounds__(kNT) void k_hop_pick(const SlotPtrs* __restrict__ s
     // far picks (position >= kSeg): direct reads, batched; the entry replaces the position in `chosen`, and a bit of
     // `farmask` (cnt <= 32) says so -- entries may carry a degree tag in their top bits, so their sign means nothing
     uint32_t farmask = 0u;
-    for (int32_t k0 = 0; k0 < cnt; k0 += 8) {
-      int32_t nb[8];
-      bool far[8];
+    for (int32_t k0 = 0; k0 < cnt; k0 += kB) {
+      int32_t nb[kB];
+      bool far[kB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kB; ++u) {
         const int32_t k = k0 + u;
         const int32_t w = (k < cnt) ? (smp ? chosen[k][tid] : k) : 0;
         far[u] = k < cnt && w >= kSeg;
         nb[u] = (int32_t)col[far[u] ? rs + w : 0];  // not predicated: lanes without a far pick share col[0]'s line
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kB; ++u)
         if (far[u]) {
           chosen[k0 + u][tid] = (int32_t)((uint32_t)nb[u] & pick_mask);
           farmask |= 1u << (k0 + u);
@@ -1111,7 +1115,11 @@ __device__ __forceinline__ int32_t first_rank(const SlotPtrs& s, uint32_t q) {
 // amdgpu_waves_per_eu(6) for the small tables: 80 registers = six workgroups of four wavefronts per compute unit, what
 // a 24 KB table admits; the allocator lands on 81 otherwise (five: the hop's launch then takes 10-60 % longer) and
 // meets 80 with one 8-byte spill in the prologue.
-template <int NS>
+// kFlat (round 6; launched when a hop's bucket spans MORE than four fine buckets: the small hops): the fine known lists are
+// walked as ONE concatenation -- entry j of it belongs to the list whose prefix interval holds j -- instead of one wavefront
+// per list, list after list: with 64 fine lists per bucket (hop 0 at papers scale) that was 16 lists per wavefront x two
+// dependent round trips each (entries, then their rank records) = 32 round trips for a handful of entries; now three.
+template <int NS, bool kFlat = false>
 __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 ? 6 : 1))) void k_bucket_dedup(const SlotPtrs* __restrict__ slots, GroupGrid gg,
                                                        int32_t hop_word, DedupGeom g, int32_t bcap, int32_t region) {
   SPP_GROUP_BLOCK(gg);
@@ -1158,7 +1166,7 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 
   // fine list -- the list's length is not known yet, entries past it are dropped; kcap >= 256)
   const int lane = threadIdx.x & (kWave - 1);
   unsigned long long kpre[4];
-  {
+  if constexpr (!kFlat) {
     const int lf0 = threadIdx.x / kWave;
     const SPP_GLOBAL unsigned long long* kl0 = known + (int64_t)(fb0 + (lf0 < nf ? lf0 : 0)) * g.kcap;
 #pragma unroll
@@ -1184,7 +1192,57 @@ __global__ __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(NS <= 3072 
   if (threadIdx.x == 0) ovf = 0;
   __syncthreads();
   // known nodes: resolve the previous hop's pending ids (its first-occurrence bitmap is overwritten by
-  // this hop's k_hop_flag, so this must happen now for EVERY list), then publish them in the LDS table;
+  // this hop's k_hop_flag, so this must happen now for EVERY list), then publish them in the LDS table
+  if constexpr (kFlat) {
+    __shared__ int32_t fpre[kMaxFinePerCoarse + 1];  // exclusive prefix of the lists' lengths
+    if (threadIdx.x < kWave) {                       // nf <= 64: one wavefront scans
+      const int32_t c = (int)threadIdx.x < nf ? fkc[threadIdx.x] : 0;
+      const int32_t inc = wave_inclusive_scan(c);
+      if ((int)threadIdx.x < nf) fpre[threadIdx.x + 1] = inc;
+      if (threadIdx.x == 0) fpre[0] = 0;
+    }
+    __syncthreads();
+    const int32_t K = fpre[nf];
+    for (int j0 = threadIdx.x; j0 < K; j0 += 4 * kNT) {  // 4 entries per thread and round, loads batched
+      unsigned long long e[4];
+      uint32_t q[4];
+      RankWord rw[4];
+      int32_t fs[4];
+      SPP_GLOBAL unsigned long long* at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int32_t j = j0 + u * kNT;
+        const int32_t jc = j < K ? j : K - 1;            // clamped, not predicated
+        int32_t lo = 0, hi = nf;                         // the list whose interval [fpre[lf], fpre[lf + 1]) holds jc
+        while (hi - lo > 1) {
+          const int32_t mid = (lo + hi) >> 1;
+          if (fpre[mid] <= jc) lo = mid; else hi = mid;
+        }
+        at[u] = known + (int64_t)(fb0 + lo) * g.kcap + (jc - fpre[lo]);
+        const unsigned long long v = *at[u];
+        e[u] = j < K ? v : kEmptySlot;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t val = (uint32_t)e[u];
+        const bool pend = e[u] != kEmptySlot && (val & kPending);
+        q[u] = pend ? (val & ~kPending) : 0u;
+        rw[u] = load_rank_word(fwords, q[u] >> 6);
+        fs[u] = fsum[q[u] >> 8];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e[u] == kEmptySlot) continue;
+        uint32_t val = (uint32_t)e[u];
+        if (val & kPending) {
+          val = Tprev + (uint32_t)(fs[u] + (int32_t)rw[u].pre + __popcll(rw[u].bits & ((1ull << (q[u] & 63)) - 1ull)));
+          e[u] = (e[u] & 0xffffffff00000000ull) | val;
+          *at[u] = e[u];
+        }
+        if (work) lds_upsert<true, NS, false>(tab, (uint32_t)(e[u] >> 32), val, &ovf);
+      }
+    }
+  } else
   // one wavefront per fine list
   for (int lf = threadIdx.x / kWave; lf < nf; lf += kNT / kWave) {
     SPP_GLOBAL unsigned long long* kl = known + (int64_t)(fb0 + lf) * g.kcap;
@@ -3194,7 +3252,14 @@ spp_status sampler_launch_chain(spp_sampler* s, int first_slot, int n, int buf, 
     // beside the delivery shrinks while its own duration grows.  Results are unchanged.
     static const unsigned dedup_pad = [] { const char* e = getenv("SPP_WHATIF_DEDUP_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
     const unsigned dpad = (h == H - 1) ? dedup_pad : 0u;
-    if (s->lds_log2 == 11)
+    // (a hop whose bucket spans more than four fine buckets walks their known lists as one concatenation: kFlat)
+    static const bool dedup_flat_on = [] { const char* e = getenv("SPP_DEDUP_FLAT"); return !e || atoi(e) != 0; }();
+    const bool flat = dedup_flat_on && (geom.nb_log2 - cb) > 2;
+    if (s->lds_log2 == 11 && flat)
+      hipLaunchKernelGGL((k_bucket_dedup<2048, true>), dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
+    else if (s->lds_log2 == 12 && flat)
+      hipLaunchKernelGGL((k_bucket_dedup<SPP_DEDUP_SLOTS12, true>), dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
+    else if (s->lds_log2 == 11)
       hipLaunchKernelGGL(k_bucket_dedup<2048>, dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
     else if (s->lds_log2 == 12)
       hipLaunchKernelGGL(k_bucket_dedup<SPP_DEDUP_SLOTS12>, dim3((nbk) * gy), dim3(kNT), dpad, st, s->d_slots, GG(nbk), hop_word, geom, bcap, region);
