@@ -866,6 +866,207 @@ def main():
     # fast_trainer/train.py:15-71): gradient all-reduces of one communicator interleave with the feature
     # exchanges of another, so the Sessions of this leg issue their exchanges from the consumer thread, at the
     # same program point on every rank (SPP_EXCHANGE_ISSUE=consumer).  All ranks take part.
+    # ---- the line, as a function: called at the end, or -- N > 1 -- by the watchdog below when an optional leg hangs ----
+    epoch_measured = model_out = p2p_out = None
+    sinfo = {}
+    legs_state = {"partial": False}
+
+    def emit_line():
+        from salient_plusplus_amd.synthetic import LOCALITY
+        locality_note = ""
+        if a.workload in LOCALITY:
+            locality_note = f" (planted {LOCALITY[a.workload][0]}-block locality, {LOCALITY[a.workload][1]:.0%} intra-block edges)"
+        if rank == 0:
+            # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
+            row_bytes = F * 2
+            # read row + write row + the index (int64 at the boundary); the assembly of the partitioned path
+            # reads an 8-byte {bucket, row} record and the row's own address instead: + 12
+            alg_bytes_per_row = 2 * row_bytes + (12 if distributed else 8)
+            # One profiled launch per batch.  N == 1: the fused delivery kernel (x-row gather + the small
+            # label gather and int64 widening of the MFG, which are charged to the gather's time but not
+            # to its bytes: conservative).  N > 1: the fused assembly kernel.
+            x_rows = rows.value
+            x_ms = ms.value
+            launches_x = n_launch.value
+            achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "k_assemble" if prof_kind == 1 else
+                    ("k_deliver (assemble from local/received/cache rows)" if distributed else "k_deliver (gather_rows_body)"),
+                    "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
+                    "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
+            # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
+            # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
+            # (the partitioned path's delivery -- assembly from {local, received, cache} rows -- has a pass of its own)
+            import glob
+            prof_dir = os.path.join(ROOT, "profiles")
+
+            def newest_first(pattern):
+                return tuple(os.path.basename(f) for f in sorted(glob.glob(os.path.join(prof_dir, pattern)), reverse=True))
+            pmc_files = newest_first("r0?_deliver_partitioned_pmc.json") if distributed else \
+                newest_first("r0?_deliver_pmc_*.json") + newest_first("r0?_gather_pmc_papers.json") + newest_first("r0?_gather_pmc.json")
+            for pmc_name in pmc_files:
+                pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+                if (distributed and not native) or not os.path.exists(pmc_path):
+                    continue
+                pmc = json.load(open(pmc_path))
+                if pmc["shape"]["row_bytes"] == row_bytes:
+                    roof["traffic"] = pmc["traffic_bytes_per_row"] * roof["rows_per_launch"]
+                    roof["traffic_source"] = (f"profiles/{pmc_name}: PMC bytes/row of this kernel from an earlier rocprofv3 "
+                                              f"--pmc pass (NOT measured in this run) x this run's rows/launch")
+                    roof["algorithmic_bytes_per_launch"] = alg_bytes_per_row * roof["rows_per_launch"]
+                    break
+            # The sampler (roofline per kernel family).  Algorithmic bytes of the batches this rank consumed in the
+            # timed region / their number = per batch; time = the in-situ span of a chain (all hops of a group of batches, first
+            # launch to last on its sampling stream, beside the delivery kernel and the chain of the other sampling stream)
+            # / the batches of the group.  traffic: per batch, from the last committed PMC passes over this command.
+            roof_s = None
+            if ch_n.value > 0 and ch_ms.value > 0:
+                alg_pb = chain_alg_bytes / max(1, a.steps * R)
+                span_pb = ch_ms.value / max(1, ch_batches.value)                 # ms of chain span per batch
+                ach = alg_pb / (span_pb * 1e-3) / 1e9
+                roof_s = {"bound": "hbm", "kernel": "sampling chain (k_seed_init, k_hop_count/pick, k_bucket_*, k_hop_flag/rows; all hops)",
+                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                          "algorithmic_bytes_per_batch": alg_pb, "chain_span_ms_per_batch": span_pb,
+                          "avg_chain_span_ms": ch_ms.value / ch_n.value, "batches_per_chain": ch_batches.value / ch_n.value,
+                          "chains_timed": ch_n.value,
+                          "note": "in-situ span on the chain's own stream: the chains of two slot-sets run concurrently on two sampling "
+                                  "streams beside the delivery kernel, so spans overlap (the per-batch cost in the step is smaller than the span)"}
+                pmc_txt = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_partitioned_pmc_traffic_per_kernel.txt" if distributed
+                                                        else "r0?_pipeline_pmc_traffic_per_kernel.txt")))
+                # (the committed passes are of S-papers with its own fan-outs: any other workload keeps "traffic": null)
+                if pmc_txt and a.workload == "S-papers" and not a.fanouts:
+                    mb = 0.0
+                    for ln in open(pmc_txt[-1]):
+                        f_ = ln.split()
+                        if ln.startswith("spp::") and "k_deliver" not in ln and len(f_) >= 4:
+                            mb += float(f_[-3]) + float(f_[-2])
+                    if mb > 0:
+                        roof_s["traffic"] = mb * 1e6
+                        roof_s["traffic_source"] = (f"profiles/{os.path.basename(pmc_txt[-1])}: fetch + write MB per batch of the chain's kernels from "
+                                                    f"earlier rocprofv3 --pmc passes over this command (NOT measured in this run)")
+            if roof_s is not None and not distributed:
+                # context for the in-situ span: the chain ALONE on the GPU (two sampling streams, no deliveries), from the
+                # committed sampling-only run of this workload's default configuration -- not measured in this run
+                lone = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_chain_only_trace_report.txt")))
+                if lone and a.workload == "S-papers" and not a.fanouts:
+                    import re
+                    m_ = re.search(r"chain only: .*?([0-9.]+) us/batch", open(lone[-1]).read())
+                    if m_:
+                        us = float(m_.group(1))
+                        roof_s["lone_chain"] = {"us_per_batch": us, "achieved_GBps_algorithmic": roof_s["algorithmic_bytes_per_batch"] / us / 1e3,
+                                                "achieved_GBps_traffic": (roof_s["traffic"] / us / 1e3) if roof_s["traffic"] else None,
+                                                "source": f"profiles/{os.path.basename(lone[-1])} (tools/microbench.py chain; NOT measured in this run)"}
+            # the step as a whole against the memory system: the HBM traffic of one batch (delivery + chain, from the committed PMC
+            # passes over this command) over the measured step
+            roof_p = None
+            if roof.get("traffic") and roof_s is not None and roof_s.get("traffic") and not distributed:
+                tot = roof["traffic"] + roof_s["traffic"]
+                ach = tot / (dt / a.steps) / 1e9
+                roof_p = {"bound": "hbm", "what": "the whole step: counter traffic of one batch's delivery + sampling chain over ms_per_step",
+                          "traffic_bytes_per_batch": tot, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                          "traffic_source": "profiles/ PMC passes (NOT measured in this run) x this run's step"}
+            out = {
+                "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64/fp16-copy",
+                "data": "synthetic",
+                "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
+                                       f"fanout {sizes}, batch {bs}, all features in HBM",
+                           "parallelism": parallelism, "slots_in_flight": a.slots,
+                           # which form of the sampling chain the library chose by itself (spp_sampler_get_info)
+                           "sampler_variant": {k_: sinfo.get(k_) for k_ in ("col32", "deg_tags", "row_stubs", "rng_arena", "idbits", "tag_cap",
+                                                                            "generic", "fused_pick", "flag_tiled", "rows_coalesced",
+                                                                            "bucket_log2", "dedup_table_slots")} if sinfo else None},
+                "windows": {"n": R, "steps_each": a.steps, "reported": "mean over all windows (timed_region_s / all steps)",
+                            "ms_per_step_min": min(window_ms), "ms_per_step_median": dt_median / a.steps * 1e3,
+                            "ms_per_step_mean": dt_mean / a.steps * 1e3,
+                            "ms_per_step_trimmed_mean": dt_trimmed / a.steps * 1e3,   # without the slowest and the fastest of >= 8 windows
+                            "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
+                            "ms_per_step_all": [round(v, 5) for v in window_ms],
+                            # sampling groups (one chain of up to 16 batches each) rank 0 opened in each window, and the windows
+                            # that opened two or more: K steps are K / 16 groups, so with K = 20 one window in four carries two
+                            # chains' work (a structural long window, not a stall)
+                            "groups_opened_all": groups_per_window,
+                            "opens_two_groups": [k for k, n_ in enumerate(groups_per_window) if n_ >= 2],
+                            # in-situ duration of the timed delivery launches of each window (rank 0; live HIP events)
+                            "deliver_us_all": [round(1e3 * (b[0] - a_[0]) / max(1, b[1] - a_[1]), 1)
+                                               for a_, b in zip([(0.0, 0)] + prof_cum[:-1], prof_cum)]},
+                "timed_region_s": timed_total_s,          # all R windows (also under "windows")
+            "optional_legs_timed_out": legs_state["partial"],   # N > 1 only: the watchdog printed this line
+                "host": {"cpu_cores_flag": a.cpu_cores, "affinity_cores": len(os.sched_getaffinity(0)), "cpu_share": host_cpu_share()},
+                "hbm": None if legs_state["partial"] else
+                       {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
+                        "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+                        "torch_alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
+                        "torch_device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)),
+                        "torch_device_allocs_in_timed_region": dev_allocs_timed},   # hipMalloc calls of the caching allocator
+                "priming_steps": max(0, a.prime),
+                "batches_per_s": a.steps * world / dt,
+                # (an EXTRAPOLATION: batches x ms/step of the windows; the measured epochs are under "epoch_measured")
+                "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
+                "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),
+                "graph_build_s": t_build,
+                # once-per-process work the timed windows lean on and never pay: the int32 neighbour array, the row stubs (both
+                # once per graph) and the mt19937 streams of the whole epoch (once per range table; the pooled sampler keeps
+                # them across epochs).  The measured epochs' FIRST epoch is where a training run would see them.
+                "setup": {"col32_ms": sinfo.get("col32_ms"), "col32_GB": (sinfo.get("col32_bytes") or 0) / 1e9,
+                          "row_stubs_ms": sinfo.get("row_stubs_ms"), "row_stubs_GB": (sinfo.get("row_stubs_bytes") or 0) / 1e9,
+                          "rng_arena_ms": sinfo.get("rng_arena_ms"), "rng_arena_GB": (sinfo.get("rng_arena_bytes") or 0) / 1e9,
+                          "rng_arena_batches": sinfo.get("rng_arena_batches"),
+                          "rng_arena_ms_per_batch_amortised_over_one_epoch":
+                              (sinfo.get("rng_arena_ms") or 0.0) / max(1, sinfo.get("rng_arena_batches") or 1),
+                          "charged_to": "neither `value` nor the windows: set-up (first Session of the process)"} if sinfo else None,
+                "epoch_measured": epoch_measured,
+                "roofline": roof,
+                "roofline_sampler": roof_s,
+                "roofline_pipeline": roof_p,
+            }
+            if distributed and native:
+                # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
+                # by up to the slot-sets in flight, so this is within one group of the bytes of the K batches)
+                sent, recv = xb1[0] - xb0[0], xb1[1] - xb0[1]
+                n_timed = a.steps * R
+                out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI",
+                                   "rccl_world": rccl_world,          # ranks the native communicator really spans
+                                   "verified_bit_exact_vs_full_table": exchange_verified,
+                                   "verified_per_rank": verified_per_rank,
+                                   "timeout_s": float(os.environ.get("SPP_EXCHANGE_TIMEOUT_S", "300")),
+                                   "rank0_sent_MB_per_batch": sent / n_timed / 1e6,
+                                   "rank0_received_MB_per_batch": recv / n_timed / 1e6,
+                                   "rank0_GBps_out": sent / timed_total_s / 1e9, "rank0_GBps_in": recv / timed_total_s / 1e9,
+                                   "xgmi_peak_GBps_per_gpu": 7 * 153.0}
+            if p2p_out is not None:
+                out["exchange_p2p"] = p2p_out
+            if model_out is not None:
+                out.update(model_out)
+            if not a.no_cpu_baseline and not distributed:
+                threads = host_cpu_share()
+                host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
+                out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
+                out["cpu_baseline"]["cores_source"] = (f"min(sched_getaffinity = {len(os.sched_getaffinity(0))}, cgroup cpu.max quota) "
+                                                       f"= {threads}; os.cpu_count() shows {os.cpu_count()}")
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            sys.stdout.flush()
+            os.write(line_fd, (json.dumps(out) + "\n").encode())
+
+    # N > 1: the legs below are optional extras behind the measured windows, and every one of them is a sequence of
+    # collectives -- a rank that falls out of step would hang the others, and the line (printed last) with it.  A watchdog
+    # prints the line with what has been measured so far (`optional_legs_timed_out`) and ends the process.
+    watchdog = None
+    if distributed:
+        import threading
+
+        def _deadline():
+            try:
+                legs_state["partial"] = True
+                if rank == 0:
+                    emit_line()
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("SPP_BENCH_LEG_TIMEOUT_S", "420")), _deadline)
+        watchdog.daemon = True
+        watchdog.start()
     model_out = None
     layers = a.layers if a.layers > 0 else len(sizes)
     n_classes = 47
@@ -1092,181 +1293,10 @@ def main():
                 v_["extrapolated_s"] = ext[k_]
                 v_["measured_over_extrapolated"] = v_["steady_s_mean"] / ext[k_]
 
-    from salient_plusplus_amd.synthetic import LOCALITY
-    locality_note = ""
-    if a.workload in LOCALITY:
-        locality_note = f" (planted {LOCALITY[a.workload][0]}-block locality, {LOCALITY[a.workload][1]:.0%} intra-block edges)"
-    if rank == 0:
-        # dominant HBM kernel: the feature-row gather (x rows dominate: y rows are 8 B each)
-        row_bytes = F * 2
-        # read row + write row + the index (int64 at the boundary); the assembly of the partitioned path
-        # reads an 8-byte {bucket, row} record and the row's own address instead: + 12
-        alg_bytes_per_row = 2 * row_bytes + (12 if distributed else 8)
-        # One profiled launch per batch.  N == 1: the fused delivery kernel (x-row gather + the small
-        # label gather and int64 widening of the MFG, which are charged to the gather's time but not
-        # to its bytes: conservative).  N > 1: the fused assembly kernel.
-        x_rows = rows.value
-        x_ms = ms.value
-        launches_x = n_launch.value
-        achieved = (x_rows * alg_bytes_per_row) / (x_ms * 1e-3) / 1e9 if x_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_assemble" if prof_kind == 1 else
-                ("k_deliver (assemble from local/received/cache rows)" if distributed else "k_deliver (gather_rows_body)"),
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_ms": x_ms / max(1, launches_x), "launches": launches_x,
-                "algorithmic_bytes_per_row": alg_bytes_per_row, "rows_per_launch": x_rows / max(1, launches_x)}
-        # HBM traffic of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE and
-        # WRITE_SIZE in separate rocprofv3 runs, corrected on a known-bytes launch of this access width)
-        # (the partitioned path's delivery -- assembly from {local, received, cache} rows -- has a pass of its own)
-        import glob
-        prof_dir = os.path.join(ROOT, "profiles")
-
-        def newest_first(pattern):
-            return tuple(os.path.basename(f) for f in sorted(glob.glob(os.path.join(prof_dir, pattern)), reverse=True))
-        pmc_files = newest_first("r0?_deliver_partitioned_pmc.json") if distributed else \
-            newest_first("r0?_deliver_pmc_*.json") + newest_first("r0?_gather_pmc_papers.json") + newest_first("r0?_gather_pmc.json")
-        for pmc_name in pmc_files:
-            pmc_path = os.path.join(ROOT, "profiles", pmc_name)
-            if (distributed and not native) or not os.path.exists(pmc_path):
-                continue
-            pmc = json.load(open(pmc_path))
-            if pmc["shape"]["row_bytes"] == row_bytes:
-                roof["traffic"] = pmc["traffic_bytes_per_row"] * roof["rows_per_launch"]
-                roof["traffic_source"] = (f"profiles/{pmc_name}: PMC bytes/row of this kernel from an earlier rocprofv3 "
-                                          f"--pmc pass (NOT measured in this run) x this run's rows/launch")
-                roof["algorithmic_bytes_per_launch"] = alg_bytes_per_row * roof["rows_per_launch"]
-                break
-        # The sampler (roofline per kernel family).  Algorithmic bytes of the batches this rank consumed in the
-        # timed region / their number = per batch; time = the in-situ span of a chain (all hops of a group of batches, first
-        # launch to last on its sampling stream, beside the delivery kernel and the chain of the other sampling stream)
-        # / the batches of the group.  traffic: per batch, from the last committed PMC passes over this command.
-        roof_s = None
-        if ch_n.value > 0 and ch_ms.value > 0:
-            alg_pb = chain_alg_bytes / max(1, a.steps * R)
-            span_pb = ch_ms.value / max(1, ch_batches.value)                 # ms of chain span per batch
-            ach = alg_pb / (span_pb * 1e-3) / 1e9
-            roof_s = {"bound": "hbm", "kernel": "sampling chain (k_seed_init, k_hop_count/pick, k_bucket_*, k_hop_flag/rows; all hops)",
-                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                      "algorithmic_bytes_per_batch": alg_pb, "chain_span_ms_per_batch": span_pb,
-                      "avg_chain_span_ms": ch_ms.value / ch_n.value, "batches_per_chain": ch_batches.value / ch_n.value,
-                      "chains_timed": ch_n.value,
-                      "note": "in-situ span on the chain's own stream: the chains of two slot-sets run concurrently on two sampling "
-                              "streams beside the delivery kernel, so spans overlap (the per-batch cost in the step is smaller than the span)"}
-            pmc_txt = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_partitioned_pmc_traffic_per_kernel.txt" if distributed
-                                                    else "r0?_pipeline_pmc_traffic_per_kernel.txt")))
-            # (the committed passes are of S-papers with its own fan-outs: any other workload keeps "traffic": null)
-            if pmc_txt and a.workload == "S-papers" and not a.fanouts:
-                mb = 0.0
-                for ln in open(pmc_txt[-1]):
-                    f_ = ln.split()
-                    if ln.startswith("spp::") and "k_deliver" not in ln and len(f_) >= 4:
-                        mb += float(f_[-3]) + float(f_[-2])
-                if mb > 0:
-                    roof_s["traffic"] = mb * 1e6
-                    roof_s["traffic_source"] = (f"profiles/{os.path.basename(pmc_txt[-1])}: fetch + write MB per batch of the chain's kernels from "
-                                                f"earlier rocprofv3 --pmc passes over this command (NOT measured in this run)")
-        if roof_s is not None and not distributed:
-            # context for the in-situ span: the chain ALONE on the GPU (two sampling streams, no deliveries), from the
-            # committed sampling-only run of this workload's default configuration -- not measured in this run
-            lone = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_chain_only_trace_report.txt")))
-            if lone and a.workload == "S-papers" and not a.fanouts:
-                import re
-                m_ = re.search(r"chain only: .*?([0-9.]+) us/batch", open(lone[-1]).read())
-                if m_:
-                    us = float(m_.group(1))
-                    roof_s["lone_chain"] = {"us_per_batch": us, "achieved_GBps_algorithmic": roof_s["algorithmic_bytes_per_batch"] / us / 1e3,
-                                            "achieved_GBps_traffic": (roof_s["traffic"] / us / 1e3) if roof_s["traffic"] else None,
-                                            "source": f"profiles/{os.path.basename(lone[-1])} (tools/microbench.py chain; NOT measured in this run)"}
-        # the step as a whole against the memory system: the HBM traffic of one batch (delivery + chain, from the committed PMC
-        # passes over this command) over the measured step
-        roof_p = None
-        if roof.get("traffic") and roof_s is not None and roof_s.get("traffic") and not distributed:
-            tot = roof["traffic"] + roof_s["traffic"]
-            ach = tot / (dt / a.steps) / 1e9
-            roof_p = {"bound": "hbm", "what": "the whole step: counter traffic of one batch's delivery + sampling chain over ms_per_step",
-                      "traffic_bytes_per_batch": tot, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                      "traffic_source": "profiles/ PMC passes (NOT measured in this run) x this run's step"}
-        out = {
-            "metric": "sampled_edges_per_sec", "value": edges / dt, "unit": "sampled-edges/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64/fp16-copy",
-            "data": "synthetic",
-            "config": {"workload": f"{a.workload}{locality_note}: N={N} nnz={int(wl.col.numel())} F={F} fp16, "
-                                   f"fanout {sizes}, batch {bs}, all features in HBM",
-                       "parallelism": parallelism, "slots_in_flight": a.slots,
-                       # which form of the sampling chain the library chose by itself (spp_sampler_get_info)
-                       "sampler_variant": {k_: sinfo.get(k_) for k_ in ("col32", "deg_tags", "row_stubs", "rng_arena", "idbits", "tag_cap",
-                                                                        "generic", "fused_pick", "flag_tiled", "rows_coalesced",
-                                                                        "bucket_log2", "dedup_table_slots")} if sinfo else None},
-            "windows": {"n": R, "steps_each": a.steps, "reported": "mean over all windows (timed_region_s / all steps)",
-                        "ms_per_step_min": min(window_ms), "ms_per_step_median": dt_median / a.steps * 1e3,
-                        "ms_per_step_mean": dt_mean / a.steps * 1e3,
-                        "ms_per_step_trimmed_mean": dt_trimmed / a.steps * 1e3,   # without the slowest and the fastest of >= 8 windows
-                        "ms_per_step_max": max(window_ms), "timed_region_s": timed_total_s,
-                        "ms_per_step_all": [round(v, 5) for v in window_ms],
-                        # sampling groups (one chain of up to 16 batches each) rank 0 opened in each window, and the windows
-                        # that opened two or more: K steps are K / 16 groups, so with K = 20 one window in four carries two
-                        # chains' work (a structural long window, not a stall)
-                        "groups_opened_all": groups_per_window,
-                        "opens_two_groups": [k for k, n_ in enumerate(groups_per_window) if n_ >= 2],
-                        # in-situ duration of the timed delivery launches of each window (rank 0; live HIP events)
-                        "deliver_us_all": [round(1e3 * (b[0] - a_[0]) / max(1, b[1] - a_[1]), 1)
-                                           for a_, b in zip([(0.0, 0)] + prof_cum[:-1], prof_cum)]},
-            "timed_region_s": timed_total_s,          # all R windows (also under "windows")
-            "host": {"cpu_cores_flag": a.cpu_cores, "affinity_cores": len(os.sched_getaffinity(0)), "cpu_share": host_cpu_share()},
-            "hbm": {"free_gb": round(torch.cuda.mem_get_info(dev)[0] / 2**30, 2), "total_gb": round(torch.cuda.mem_get_info(dev)[1] / 2**30, 2),
-                    "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 2**30, 2),
-                    "torch_alloc_retries": int(torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)),
-                    "torch_device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0)),
-                    "torch_device_allocs_in_timed_region": dev_allocs_timed},   # hipMalloc calls of the caching allocator
-            "priming_steps": max(0, a.prime),
-            "batches_per_s": a.steps * world / dt,
-            # (an EXTRAPOLATION: batches x ms/step of the windows; the measured epochs are under "epoch_measured")
-            "epoch_time_s_data_path_only": (wl.train_idx.numel() // bs) / (a.steps / dt) if not distributed else None,
-            "mfg_nodes_per_batch": nodes / (a.steps * world), "sampled_edges_per_batch": edges / (a.steps * world),
-            "graph_build_s": t_build,
-            # once-per-process work the timed windows lean on and never pay: the int32 neighbour array, the row stubs (both
-            # once per graph) and the mt19937 streams of the whole epoch (once per range table; the pooled sampler keeps
-            # them across epochs).  The measured epochs' FIRST epoch is where a training run would see them.
-            "setup": {"col32_ms": sinfo.get("col32_ms"), "col32_GB": (sinfo.get("col32_bytes") or 0) / 1e9,
-                      "row_stubs_ms": sinfo.get("row_stubs_ms"), "row_stubs_GB": (sinfo.get("row_stubs_bytes") or 0) / 1e9,
-                      "rng_arena_ms": sinfo.get("rng_arena_ms"), "rng_arena_GB": (sinfo.get("rng_arena_bytes") or 0) / 1e9,
-                      "rng_arena_batches": sinfo.get("rng_arena_batches"),
-                      "rng_arena_ms_per_batch_amortised_over_one_epoch":
-                          (sinfo.get("rng_arena_ms") or 0.0) / max(1, sinfo.get("rng_arena_batches") or 1),
-                      "charged_to": "neither `value` nor the windows: set-up (first Session of the process)"} if sinfo else None,
-            "epoch_measured": epoch_measured,
-            "roofline": roof,
-            "roofline_sampler": roof_s,
-            "roofline_pipeline": roof_p,
-        }
-        if distributed and native:
-            # rank 0's share of the exchange over the timed region (the exchange runs ahead of the consumer
-            # by up to the slot-sets in flight, so this is within one group of the bytes of the K batches)
-            sent, recv = xb1[0] - xb0[0], xb1[1] - xb0[1]
-            n_timed = a.steps * R
-            out["exchange"] = {"transport": "RCCL grouped send/recv over xGMI",
-                               "rccl_world": rccl_world,          # ranks the native communicator really spans
-                               "verified_bit_exact_vs_full_table": exchange_verified,
-                               "verified_per_rank": verified_per_rank,
-                               "timeout_s": float(os.environ.get("SPP_EXCHANGE_TIMEOUT_S", "300")),
-                               "rank0_sent_MB_per_batch": sent / n_timed / 1e6,
-                               "rank0_received_MB_per_batch": recv / n_timed / 1e6,
-                               "rank0_GBps_out": sent / timed_total_s / 1e9, "rank0_GBps_in": recv / timed_total_s / 1e9,
-                               "xgmi_peak_GBps_per_gpu": 7 * 153.0}
-        if p2p_out is not None:
-            out["exchange_p2p"] = p2p_out
-        if model_out is not None:
-            out.update(model_out)
-        if not a.no_cpu_baseline and not distributed:
-            threads = host_cpu_share()
-            host = (wl.rowptr.cpu(), wl.col.cpu(), wl.x.cpu(), wl.y.cpu(), shuffler.get_idx().cpu())
-            out["cpu_baseline"] = cpu_baseline(host, sizes, bs, a.cpu_seconds, threads)
-            out["cpu_baseline"]["cores_source"] = (f"min(sched_getaffinity = {len(os.sched_getaffinity(0))}, cgroup cpu.max quota) "
-                                                   f"= {threads}; os.cpu_count() shows {os.cpu_count()}")
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        sys.stdout.flush()
-        os.write(line_fd, (json.dumps(out) + "\n").encode())
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0 and not legs_state["partial"]:
+        emit_line()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

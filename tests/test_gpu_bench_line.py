@@ -16,8 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra):
+def _run(extra, more_env=None):
     env = dict(os.environ)
+    env.update(more_env or {})
     env.setdefault("MASTER_PORT", "29741")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "S-arxiv", "--steps", "24", "--warmup", "2",
                         "--windows", "2", "--prime", "8", "--cpu-seconds", "1"] + extra, env=env, capture_output=True, text=True,
@@ -125,3 +126,11 @@ def test_model_shape_flags():
     m = d["model_step"]
     assert m["hidden"] == 1024 and m["layers"] == 2 and "SAGE 2x1024" in m["model"] and m["ms_per_step_with_data_path"] > 0
     assert d["epoch_measured"] is None
+
+
+def test_partitioned_line_survives_an_optional_leg_that_never_returns():
+    """N > 1 (here: the partitioned path at world size 1): the legs behind the timed windows are sequences of collectives; if one
+    hangs, a watchdog prints the line with what the windows measured and ends the process (SPP_BENCH_LEG_TIMEOUT_S)."""
+    d = _run(["--gpus", "1", "--force-distributed", "--no-cpu-baseline"], {"SPP_BENCH_LEG_TIMEOUT_S": "0.2"})
+    assert d["optional_legs_timed_out"] is True and d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["frac"] > 0
+    assert "range-partitioned" in d["config"]["parallelism"]
